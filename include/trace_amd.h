@@ -1,0 +1,259 @@
+/*
+ * trace_amd.h — C-ABI of libtrace_amd.so: the MI355X (gfx950) implementation of
+ * TRACE's per-clip video-relation hot path.
+ *
+ * Conventions:
+ *   - every entry point returns 0 on success, nonzero on error; the message is
+ *     available from trace_last_error() (thread-local);
+ *   - all data pointers are DEVICE pointers owned by the caller; nothing is
+ *     allocated inside (workspaces are passed in, sizes come from the
+ *     trace_*_workspace_bytes helpers); no host synchronisation;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - bf16 tensors are passed as `const uint16_t*` (raw bfloat16 bits).
+ *
+ * Each declaration cites the reference interface (file:line under
+ * /root/reference) it replaces.
+ */
+#ifndef TRACE_AMD_H
+#define TRACE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* trace_stream_t;
+
+/* Library/version probes. */
+const char* trace_last_error(void);
+int trace_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* ROIAlign / ROIPool: Detectron_pytorch/lib/model/csrc/vision.cpp:7-13      */
+/* ------------------------------------------------------------------------ */
+
+/* _C.roi_align_forward — csrc/ROIAlign.h:11-25, cuda/ROIAlign_cuda.cu:64-122,
+ * cpu/ROIAlign_cpu.cpp:113-219.  input (B,C,H,W) f32 NCHW, rois (K,5)
+ * [batch,x1,y1,x2,y2] f32, out (K,C,PH,PW) f32.  sampling_ratio<=0 = adaptive
+ * ceil(roi/pooled) grid.  Arithmetic order follows the CPU reference (no FMA
+ * contraction) so results are bit-identical to it. */
+int trace_roi_align_fwd_f32(const float* input, int B, int C, int H, int W,
+                            const float* rois, int K, float spatial_scale,
+                            int pooled_h, int pooled_w, int sampling_ratio,
+                            float* out, trace_stream_t stream);
+
+/* _C.roi_align_backward — csrc/ROIAlign.h:27-45, cuda/ROIAlign_cuda.cu:177-254,
+ * 302-346.  grad (K,C,PH,PW) f32 -> grad_input (B,C,H,W) f32 (zeroed here, on
+ * `stream`, then accumulated with float atomics as the reference does). */
+int trace_roi_align_bwd_f32(const float* grad, const float* rois, int K,
+                            float spatial_scale, int pooled_h, int pooled_w,
+                            int B, int C, int H, int W, int sampling_ratio,
+                            float* grad_input, trace_stream_t stream);
+
+/* _C.roi_pool_forward — csrc/ROIPool.h:11-25, cuda/ROIPool_cuda.cu:16-77.
+ * out (K,C,PH,PW) f32, argmax (K,C,PH,PW) int32 (index into the H*W plane,
+ * -1 when the bin is empty). */
+int trace_roi_pool_fwd_f32(const float* input, int B, int C, int H, int W,
+                           const float* rois, int K, float spatial_scale,
+                           int pooled_h, int pooled_w, float* out,
+                           int32_t* argmax, trace_stream_t stream);
+
+/* _C.roi_pool_backward — csrc/ROIPool.h:27-46, cuda/ROIPool_cuda.cu:79-108. */
+int trace_roi_pool_bwd_f32(const float* grad, const int32_t* argmax,
+                           const float* rois, int K, int pooled_h,
+                           int pooled_w, int B, int C, int H, int W,
+                           float* grad_input, trace_stream_t stream);
+
+/* MI355X-native layout variant of roi_align_forward used inside the fused
+ * pipeline: input (B,H,W,C) bf16 channels-last, out (K,PH,PW,C) bf16; same
+ * sampling rule as above, f32 accumulation.  Replaces the per-call
+ * `torch.from_numpy(rois).cuda()` + NCHW gather at
+ * lib/modeling_rel/model_builder_rel.py:1389-1394 and
+ * lib/combine_tree/cluster_tree.py:729-732.  C must be a multiple of 8. */
+int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H, int W,
+                                  int C, const float* rois, int K,
+                                  float spatial_scale, int pooled_h,
+                                  int pooled_w, int sampling_ratio,
+                                  uint16_t* out, trace_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* NMS: csrc/nms.h:10-28 (_C.nms), cpu/nms_cpu.cpp:5-65, cuda/nms.cu:23-131, */
+/*      and the run-time path Detectron_pytorch/lib/utils/cython_nms.pyx:37-87 */
+/* ------------------------------------------------------------------------ */
+#define TRACE_NMS_GE 0 /* suppress if IoU >= thresh (Cython / CPU reference) */
+#define TRACE_NMS_GT 1 /* suppress if IoU >  thresh (CUDA reference)          */
+
+size_t trace_nms_workspace_bytes(int n_boxes);
+
+/* boxes (N,4) f32 [x1,y1,x2,y2], scores (N,) f32.  Greedy NMS in descending
+ * score order (ties: lower index first), "+1" areas, f32 IoU exactly as the
+ * reference.  keep_out receives the kept ORIGINAL indices in ascending order
+ * (cython_nms.pyx:87, nms.cu:127-130), *num_keep (device int32) their count. */
+int trace_nms(const float* boxes, const float* scores, int N, float thresh,
+              int mode, int64_t* keep_out, int32_t* num_keep, void* workspace,
+              size_t workspace_bytes, trace_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Box helpers                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* utils.fpn.map_rois_to_fpn_levels — Detectron_pytorch/lib/utils/fpn.py:11-28
+ * (+ boxes_area, utils/boxes.py:58-73).  rois (N,4) f32 -> levels (N,) f32. */
+int trace_fpn_levels(const float* boxes, int N, int k_min, int k_max,
+                     float canonical_scale, float canonical_level,
+                     float* levels, trace_stream_t stream);
+
+/* cython_bbox.bbox_overlaps — Detectron_pytorch/lib/utils/cython_bbox.pyx:32-73.
+ * boxes (N,4), query (K,4) -> overlaps (N,K) f32. */
+int trace_bbox_overlaps(const float* boxes, int N, const float* query, int K,
+                        float* overlaps, trace_stream_t stream);
+
+/* cython_bbox_rel.bbox_pair_overlaps — lib/utils_rel/cython_bbox_rel.pyx:37-77. */
+int trace_bbox_pair_overlaps(const float* boxes1, const float* boxes2, int N,
+                             float* overlaps, trace_stream_t stream);
+
+/* RelPN pair enumeration + union rois — lib/modeling_rel/relpn_heads.py:79-84,
+ * 39-46, 117 and lib/utils_rel/boxes_rel.py:100-106.  det_rois (n,5) ->
+ * sbj_inds/obj_inds (P,) int32, rel_rois (P,5) f32, P = n*(n-1) (n if n==1). */
+int trace_relpn_pairs(const float* det_rois, int n, int32_t* sbj_inds,
+                      int32_t* obj_inds, float* rel_rois,
+                      trace_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* I3D backbone: lib/i3d/resnet3d.py:155-318, 718-802 (+ mmcv ConvModule /   */
+/* NonLocal3d call sites resnet3d.py:95,250,262,275,289,549,721)             */
+/* ------------------------------------------------------------------------ */
+
+/* (N,C,T,H,W) or (N,T,C,H,W) f32 clip -> channels-last bf16
+ * (N, pt0+T+pt1, ph0+H+ph1, pw0+W+pw1, Cp): channel dim zero-padded to Cp and a
+ * zero halo written around T/H/W so that the stem conv needs no bounds checks;
+ * replaces the permute at lib/modeling_rel/model_builder_rel.py:978.
+ * in_ntchw!=0 selects the (N,T,C,H,W) input order (the layout all_frames
+ * arrives in, :688). */
+int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
+                             int W, int in_ntchw, int Cp, int pt0, int pt1,
+                             int ph0, int ph1, int pw0, int pw1, uint16_t* out,
+                             trace_stream_t stream);
+
+#define TRACE_EPI_RELU 1     /* ReLU after bias(+residual)                   */
+#define TRACE_EPI_RESIDUAL 2 /* add `residual` (same shape as out) first     */
+#define TRACE_EPI_OUT_F32 4  /* write f32 instead of bf16                    */
+
+/* Conv3d + folded eval-mode BatchNorm3d (+residual)(+ReLU) as an implicit GEMM
+ * on bf16 MFMA (mmcv ConvModule at resnet3d.py:250-283,549-557,721-730;
+ * residual add + ReLU resnet3d.py:306,313).
+ *   in   (N,Ti,Hi,Wi,Cin)  bf16 channels-last, Cin % 8 == 0
+ *   w    (Cout, kt*kh*kw*Cin) bf16, tap-major / channel-minor, BN scale folded
+ *   bias (Cout) f32 (BN shift, or conv bias)
+ *   out  (N,To,Ho,Wo,Cout) bf16 (or f32 with TRACE_EPI_OUT_F32), Cout % 8 == 0 */
+int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi, int Wi,
+                            int Cin, const uint16_t* w, const float* bias,
+                            int Cout, int kt, int kh, int kw, int st, int sh,
+                            int sw, int pt, int ph, int pw, int dt, int dh,
+                            int dw, const uint16_t* residual, int epilogue,
+                            void* out, trace_stream_t stream);
+
+/* The I3D stem (resnet3d.py:721-730: Conv3d 3->64, k(5,7,7), s(2,2,2)) on the
+ * halo-padded channels-last clip written by trace_clip_to_ndhwc_bf16: Cin=3 is
+ * far too thin for an MFMA K-step, so one (kt,kh) tap is taken as the contiguous
+ * run of kwp pixels x Cp channels (kwp*Cp % 8 == 0; weights packed
+ * (Cout, kt*kh*kwp*Cp) with zeros in the padding slots).  `st` may fold the
+ * temporal stride of the following MaxPool3d(kernel_t=1, stride_t=2)
+ * (resnet3d.py:732-735), whose skipped frames are never computed. */
+int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, int Hp,
+                           int Wp, int Cp, const uint16_t* w,
+                           const float* bias, int Cout, int kt, int kh,
+                           int kwp, int st, int sh, int sw, int To, int Ho,
+                           int Wo, int epilogue, void* out,
+                           trace_stream_t stream);
+
+/* nn.MaxPool3d on channels-last bf16 (resnet3d.py:732-737; mmcv NonLocal3d
+ * sub_sample pool).  Padding is implicit -inf as in torch. */
+int trace_maxpool3d_ndhwc_bf16(const uint16_t* in, int N, int Ti, int Hi,
+                               int Wi, int C, int kt, int kh, int kw, int st,
+                               int sh, int sw, int pt, int ph, int pw,
+                               uint16_t* out, trace_stream_t stream);
+
+/* Batched bf16 GEMM  C[b] = alpha * A[b] (M,K) * B[b]^T (N,K)  (+bias)(+res)
+ * (+ReLU); row strides lda/ldb/ldc in elements, batch strides in elements.
+ * Used for the non-local dot-product attention (mmcv NonLocal3d.dot_product:
+ * pairwise = theta^T phi / N_kv ; y = pairwise g) and every Linear layer of the
+ * relation head.  K % 8 == 0, lda/ldb % 8 == 0. */
+int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
+                       int K, int lda, int ldb, int ldc, int batch,
+                       long long strideA, long long strideB, long long strideC,
+                       float alpha, const float* bias,
+                       const uint16_t* residual, int epilogue, void* C,
+                       trace_stream_t stream);
+
+/* bf16 (rows, cols) -> bf16 (cols, rows) per batch; used to form g^T / phi for
+ * the non-local block without leaving channels-last. */
+int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int cols,
+                         uint16_t* out, trace_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Context aggregation / relation head                                       */
+/* ------------------------------------------------------------------------ */
+
+/* cluster_tree3d.temporal_{obj,r}_attention — lib/combine_tree/
+ * cluster_tree3d.py:337-366.  qs (n,D) f32 = W_s s ; qo (n,T,D) f32 = W_o o_t ;
+ * o (n,T,K) f32 ; out (n,K) f32 = sum_t softmax_t(qs.qo_t/sqrt(D)) o_t. */
+int trace_temporal_attention(const float* qs, const float* qo, const float* o,
+                             int n, int T, int D, int K, float inv_sqrt_d,
+                             float* out, trace_stream_t stream);
+
+/* Fused target-adaptive pair attention — lib/modeling_rel/
+ * model_builder_rel.py:1524-1612 (get_spatio_atten_feat, get_rel_rois,
+ * get_attention_mask_map): for every pair p, ROIAlign (adaptive grid) of the
+ * K-map and V-map (B,H,W,D) bf16 on the union box of (sbj,obj), scores
+ * q_s.K / q_o.K over the PH*PW cells, softmax, multiply into V.
+ * Outputs s_map, o_map, v_map (P,PH*PW,D) bf16 — never materialising the
+ * pooled K-map in HBM. */
+int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap,
+                               int B, int H, int W, int D,
+                               const float* rel_rois, const int32_t* sbj_inds,
+                               const int32_t* obj_inds, int P,
+                               const float* q_s, const float* q_o,
+                               float spatial_scale, int pooled,
+                               uint16_t* s_map, uint16_t* o_map,
+                               uint16_t* v_map, trace_stream_t stream);
+
+/* Tree-GRU message passing — lib/combine_tree/cluster_tree.py:163-204
+ * (forward_v1), 281-316 (bottom-up), 318-330 (top-down, 'tree' mode), for a
+ * forest of per-clip box trees and all feature groups in one launch.  The
+ * reference's dense adjacency masks (cluster_tree.py:206-215, uploaded 8x per
+ * clip) are replaced by parent / CSR child lists built once.
+ *   x (n_nodes, n_groups*F) f32 — group g reads columns [g*F,(g+1)*F)
+ *   tree t owns nodes [tree_off[t], tree_off[t+1]); inside a tree nodes are
+ *   numbered leaves first, then layer by layer (the reference numbering), and
+ *   level l of tree t is the node range
+ *   [level_off[t*(TRACE_TREE_MAX_LEVELS+1)+l], level_off[...+l+1]) (global ids)
+ *   parent (n_nodes) global id or -1; children of node v are
+ *   child_idx[child_off[v] .. child_off[v+1])
+ *   h, hd (n_nodes, n_groups*Hd) f32 outputs (bottom-up / top-down states).
+ * Weight matrices are passed TRANSPOSED, i.e. (in_features, Hd) row-major. */
+#define TRACE_TREE_MAX_LEVELS 12
+#define TRACE_TREE_MAX_GROUPS 8
+typedef struct trace_tree_gru_weights {
+  /* bottom-up: Wz,Wr,Wh (F,Hd); Uz,Ur,Uh (Hd,Hd) [transposed]; bz,br (Hd) = Uz/Ur bias */
+  const float *Wz, *Wr, *Wh, *Uz, *Ur, *Uh, *bz, *br;
+  /* top-down: Wzd.. as above */
+  const float *Wzd, *Wrd, *Whd, *Uzd, *Urd, *Uhd, *bzd, *brd;
+} trace_tree_gru_weights;
+
+int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups,
+                   int n_trees, const int32_t* tree_off,
+                   const int32_t* level_off, const int32_t* n_levels,
+                   const int32_t* parent, const int32_t* child_off,
+                   const int32_t* child_idx,
+                   const trace_tree_gru_weights* weights /* host, n_groups */,
+                   float* h, float* hd,
+                   float* workspace /* n_nodes*n_groups*Hd f32 */,
+                   trace_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACE_AMD_H */

@@ -1,0 +1,208 @@
+"""TEST INFRASTRUCTURE ONLY — numpy restatements of the reference's numpy glue.
+
+The reference's Python cannot be imported in the build container (torch._six,
+mmcv, torchvision, cv2 and the Cython extensions are absent), so these follow
+the cited source lines expression by expression; they are pinned only by that
+construction ("parity unpinned" by execution).
+"""
+import math
+
+import numpy as np
+
+
+def boxes_area(boxes):
+    """Detectron_pytorch/lib/utils/boxes.py:58-73."""
+    w = (boxes[:, 2] - boxes[:, 0] + 1)
+    h = (boxes[:, 3] - boxes[:, 1] + 1)
+    areas = w * h
+    neg_area_idx = np.where(areas < 0)[0]
+    return areas, neg_area_idx
+
+
+def map_rois_to_fpn_levels(rois, k_min, k_max, s0=224, lvl0=4):
+    """Detectron_pytorch/lib/utils/fpn.py:11-28 (cfg.FPN.ROI_CANONICAL_SCALE=224,
+    ROI_CANONICAL_LEVEL=4, lib/core/config.py)."""
+    areas, neg_idx = boxes_area(rois)
+    areas[neg_idx] = 0
+    s = np.sqrt(areas)
+    target_lvls = np.floor(lvl0 + np.log2(s / s0 + 1e-6))
+    target_lvls = np.clip(target_lvls, k_min, k_max)
+    return target_lvls
+
+
+def add_multilevel_roi_blobs(blobs, blob_prefix, rois, target_lvls, lvl_min, lvl_max):
+    """Detectron_pytorch/lib/utils/fpn.py:31-58."""
+    rois_idx_order = np.empty((0,))
+    rois_stacked = np.zeros((0, 5), dtype=np.float32)
+    for lvl in range(lvl_min, lvl_max + 1):
+        idx_lvl = np.where(target_lvls == lvl)[0]
+        blobs[blob_prefix + '_fpn' + str(lvl)] = rois[idx_lvl, :]
+        rois_idx_order = np.concatenate((rois_idx_order, idx_lvl))
+        rois_stacked = np.vstack([rois_stacked, blobs[blob_prefix + '_fpn' + str(lvl)]])
+    rois_idx_restore = np.argsort(rois_idx_order).astype(np.int32, copy=False)
+    blobs[blob_prefix + '_idx_restore_int32'] = rois_idx_restore
+    assert (rois_stacked[rois_idx_restore] == rois).all()
+    return blobs
+
+
+def rois_union(rois1, rois2):
+    """lib/utils_rel/boxes_rel.py:100-106."""
+    assert (rois1[:, 0] == rois2[:, 0]).all()
+    xmin = np.minimum(rois1[:, 1], rois2[:, 1])
+    ymin = np.minimum(rois1[:, 2], rois2[:, 2])
+    xmax = np.maximum(rois1[:, 3], rois2[:, 3])
+    ymax = np.maximum(rois1[:, 4], rois2[:, 4])
+    return np.vstack((rois1[:, 0], xmin, ymin, xmax, ymax)).transpose()
+
+
+def relpn_pairs(det_rois):
+    """lib/modeling_rel/relpn_heads.py:79-88,117 (+ remove_self_pairs :39-46)."""
+    n = det_rois.shape[0]
+    sbj_inds = np.repeat(np.arange(n), n)
+    obj_inds = np.tile(np.arange(n), n)
+    if n > 1:
+        mask = np.ones(sbj_inds.shape[0], dtype=bool)
+        for i in range(n):
+            mask[i + n * i] = False
+        keeps = np.where(mask)[0]
+        sbj_inds = sbj_inds[keeps]
+        obj_inds = obj_inds[keeps]
+    sbj_rois = det_rois[sbj_inds]
+    obj_rois = det_rois[obj_inds]
+    rel_rois = rois_union(sbj_rois, obj_rois)
+    return sbj_inds, obj_inds, rel_rois
+
+
+# ---------------------------------------------------------------------------
+# Hierarchical box tree: lib/combine_tree/cluster_tree.py:504-649, 400-430
+# ---------------------------------------------------------------------------
+def _get_distance(x, y):
+    return ((x - y) ** 2).sum(-1)  # cluster_tree.py:610-611 ('euclid')
+
+
+def _get_cluster(ids, bbox_feat):
+    """cluster_tree.py:595-607."""
+    X, Y = np.meshgrid(ids, ids, indexing='ij')
+    distance = _get_distance(bbox_feat[X], bbox_feat[Y])
+    distance = distance.reshape(len(ids), -1)
+    score = -np.sum(np.exp(-distance), axis=1)
+    id_id = np.argsort(score)
+    ids = ids[id_id]
+    c_id = [i for i in range(0, len(ids), 2)]
+    not_c_id = [i for i in range(1, len(ids), 2)]
+    return np.hstack((ids[c_id], ids[not_c_id]))
+
+
+def _cluster_algorithm(bbox_feat, cluster_num, l, r):
+    """cluster_tree.py:558-593."""
+    ids = np.arange(l, r + 1)
+    ids = _get_cluster(ids, bbox_feat)
+    cluster_id = ids[:cluster_num]
+    combine_id = ids[cluster_num:]
+    combine_flat, cluster_flat = np.meshgrid(combine_id, cluster_id)
+    combine_flat = combine_flat.reshape(-1)
+    cluster_flat = cluster_flat.reshape(-1)
+    distance = _get_distance(bbox_feat[cluster_flat], bbox_feat[combine_flat])
+    distance = distance.reshape(cluster_num, -1)
+    depend_id = np.argmin(distance, axis=0) if distance.shape[1] else np.zeros((0,), np.int64)
+    new_node = {}
+    for i in range(cluster_num):
+        new_node[r + 1 + i] = [cluster_id[i]]
+    combine_len = r - l + 1 - cluster_num
+    for i in range(combine_len):
+        new_node[r + 1 + depend_id[i]].append(combine_id[i])
+    return new_node
+
+
+def _get_new_bbox_feat(ori, new_node_dict):
+    """cluster_tree.py:617-628 ('coordinate')."""
+    new_node_feat = []
+    for head, son_list in new_node_dict.items():
+        son_feat = ori[son_list]
+        new_node_feat.append(np.array([son_feat[:, 0].min(), son_feat[:, 1].min(),
+                                       son_feat[:, 2].max(), son_feat[:, 3].max()]))
+    new_node_feat = np.stack(new_node_feat, axis=0)
+    return np.vstack((ori, new_node_feat))
+
+
+def node_cluster(leaf_boxes, max_tree_height=7, partition=2):
+    """cluster_tree.py:504-556 for ONE image (batch handled by the caller).
+    leaf_boxes (n,4) -> (layer list of {parent: [children]}, tree boxes (n+m,4))."""
+    n = leaf_boxes.shape[0]
+    layers = []
+    cluster_num = int(math.ceil(n))
+    bbox_feat = leaf_boxes.copy()
+    l, r = 0, cluster_num - 1
+    for _ in range(max_tree_height):
+        cluster_num = int(math.ceil(float(cluster_num) / partition))
+        new_node = _cluster_algorithm(bbox_feat, cluster_num, l, r)
+        layers.append(new_node)
+        bbox_feat = _get_new_bbox_feat(bbox_feat, new_node)
+        l = r + 1
+        r = r + cluster_num
+        if cluster_num <= 1:
+            break
+    if cluster_num > 1:
+        new_node = _cluster_algorithm(bbox_feat, 1, l, r)
+        layers.append(new_node)
+        bbox_feat = _get_new_bbox_feat(bbox_feat, new_node)
+    return layers, bbox_feat
+
+
+def get_A_and_link(n_tree, layers):
+    """cluster_tree.py:400-430 for one image."""
+    A_T = np.zeros((n_tree, n_tree), dtype=np.float32)
+    A = np.zeros((n_tree, n_tree), dtype=np.float32)
+    layer_list = layers[::-1]
+    link = (-1) * np.ones((n_tree, len(layer_list) + 1), dtype=np.int64)
+    link[n_tree - 1, len(layer_list)] = n_tree - 1
+    j = len(layer_list) - 1
+    for layer in layer_list:
+        for fa, son in layer.items():
+            A_T[fa, son] = 1.0
+            A[son, fa] = 1.0
+            link[son, j + 1:] = link[fa, j + 1:]
+            link[son, j] = son
+        j = j - 1
+    return A, A_T, link
+
+
+def get_lca(X, Y, link_mat):
+    """lib/modeling_rel/model_builder_rel.py:1614-1619."""
+    pos = (link_mat[X] != link_mat[Y]) * link_mat[X]
+    pos = pos.argmax(1) + 1
+    x_link_mat = link_mat[X]
+    return x_link_mat[range(len(pos)), pos]
+
+
+def temporal_nonleaf_rois(layers, n_tree, n_leaf, temporal_boxes):
+    """lib/combine_tree/cluster_tree3d.py:368-391 for one image ('coordinate').
+    temporal_boxes (n,T,4) -> (m,T,4) hull boxes of the non-leaf nodes."""
+    T = temporal_boxes.shape[1]
+    new_node_feat = np.zeros((n_tree, T, 4), dtype=np.float32)
+    new_node_feat[:n_leaf] = temporal_boxes
+    out = []
+    for layer in layers:
+        for fa, son in layer.items():
+            son_feat = new_node_feat[np.array(son)]
+            head = np.array([son_feat[:, :, 0].min(0), son_feat[:, :, 1].min(0),
+                             son_feat[:, :, 2].max(0), son_feat[:, :, 3].max(0)])
+            new_node_feat[fa] = np.transpose(head)
+            out.append(new_node_feat[fa])
+    return np.stack(out, axis=0)
+
+
+def topk_triplets(prd_scores, sbj_scores, obj_scores, prd_k, topk):
+    """lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-250 ranking core:
+    per pair take the prd_k best predicates, score = sbj*obj*prd, global top-k.
+    Returns (scores, pair index, predicate index) sorted by descending score."""
+    det_scores_prd = prd_scores  # (P, n_prd)
+    det_labels_prd = np.argsort(-det_scores_prd, axis=1)
+    det_scores_prd = -np.sort(-det_scores_prd, axis=1)
+    det_scores_so = sbj_scores * obj_scores
+    det_scores_spo = det_scores_so[:, None] * det_scores_prd[:, :prd_k]
+    flat = det_scores_spo.ravel()
+    order = np.argsort(-flat, kind='stable')[:topk]
+    pair = order // prd_k
+    slot = order % prd_k
+    return flat[order], pair, det_labels_prd[pair, slot]

@@ -1,0 +1,113 @@
+"""Mirror of the reference's `model._C` extension surface
+(Detectron_pytorch/lib/model/csrc/vision.cpp:7-13) on top of libtrace_amd.so.
+
+Same function names, argument order and error behaviour (RuntimeError) as the
+pybind module; tensors must be float32 and live on the GPU.
+"""
+import torch
+
+from . import _lib as L
+
+
+def _f32(t, name):
+    L.require_gpu(t)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t.contiguous()  # ROIAlign_cuda.cu:286,294
+
+
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
+    """vision.cpp:9 / ROIAlign.h:11-25 — returns (K,C,PH,PW)."""
+    input = _f32(input, "input")
+    rois = _f32(rois, "rois")
+    if rois.dim() != 2 or rois.size(1) != 5:
+        raise RuntimeError("rois must be (K,5)")
+    B, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(input.device):
+        L.check(L.lib().trace_roi_align_fwd_f32(L.ptr(input), B, C, H, W, L.ptr(rois), K,
+                                                float(spatial_scale), int(pooled_height),
+                                                int(pooled_width), int(sampling_ratio), L.ptr(out),
+                                                L.stream()), "roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
+                       height, width, sampling_ratio):
+    """vision.cpp:10 / ROIAlign.h:27-45 — returns (B,C,H,W)."""
+    grad = _f32(grad, "grad")
+    rois = _f32(rois, "rois")
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        L.check(L.lib().trace_roi_align_bwd_f32(L.ptr(grad), L.ptr(rois), rois.size(0),
+                                                float(spatial_scale), int(pooled_height),
+                                                int(pooled_width), int(batch_size), int(channels),
+                                                int(height), int(width), int(sampling_ratio),
+                                                L.ptr(gin), L.stream()), "roi_align_backward")
+    return gin
+
+
+def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
+    """vision.cpp:11 / ROIPool.h:11-25 — returns (output, argmax int32)."""
+    input = _f32(input, "input")
+    rois = _f32(rois, "rois")
+    B, C, H, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    argmax = torch.zeros((K, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
+    if out.numel() == 0:
+        return out, argmax
+    with torch.cuda.device(input.device):
+        L.check(L.lib().trace_roi_pool_fwd_f32(L.ptr(input), B, C, H, W, L.ptr(rois), K,
+                                               float(spatial_scale), int(pooled_height),
+                                               int(pooled_width), L.ptr(out), L.ptr(argmax),
+                                               L.stream()), "roi_pool_forward")
+    return out, argmax
+
+
+def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width,
+                      batch_size, channels, height, width):
+    """vision.cpp:12 / ROIPool.h:27-46 — returns (B,C,H,W)."""
+    grad = _f32(grad, "grad")
+    rois = _f32(rois, "rois")
+    L.require_gpu(argmax)
+    argmax = argmax.contiguous()
+    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        L.check(L.lib().trace_roi_pool_bwd_f32(L.ptr(grad), L.ptr(argmax), L.ptr(rois), rois.size(0),
+                                               int(pooled_height), int(pooled_width), int(batch_size),
+                                               int(channels), int(height), int(width), L.ptr(gin),
+                                               L.stream()), "roi_pool_backward")
+    return gin
+
+
+NMS_GE = 0  # Cython / CPU reference semantics (cython_nms.pyx:84, nms_cpu.cpp:60)
+NMS_GT = 1  # CUDA reference semantics (cuda/nms.cu:60)
+
+
+def nms(dets, scores, threshold, mode=NMS_GE):
+    """vision.cpp:8 / nms.h:10-28 — dets (N,4), scores (N,) -> int64 keep indices.
+
+    Returns kept original indices in ascending order on the dets' device (empty
+    input -> empty CPU tensor as nms.h:17-18).  `mode` selects the reference's
+    CPU (>=, default: the path TRACE actually runs) or CUDA (>) comparison.
+    """
+    if dets.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device="cpu")
+    dets = _f32(dets, "dets")
+    scores = _f32(scores, "scores")
+    if dets.dim() != 2 or dets.size(1) != 4 or scores.numel() != dets.size(0):
+        raise RuntimeError("nms expects dets (N,4) and scores (N,)")
+    N = dets.size(0)
+    lib = L.lib()
+    ws_bytes = lib.trace_nms_workspace_bytes(N)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dets.device)
+    keep = torch.empty((N,), dtype=torch.int64, device=dets.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    with torch.cuda.device(dets.device):
+        L.check(lib.trace_nms(L.ptr(dets), L.ptr(scores), N, float(threshold), int(mode), L.ptr(keep),
+                              L.ptr(num), L.ptr(ws), ws_bytes, L.stream()), "nms")
+    return keep[: int(num.item())]

@@ -1,0 +1,94 @@
+"""ctypes binding of libtrace_amd.so (the C-ABI declared in include/trace_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or a tensor is not on a
+GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtrace_amd.so")
+
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+c_longlong = ctypes.c_longlong
+
+
+class TreeGruWeights(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("Wz", "Wr", "Wh", "Uz", "Ur", "Uh", "bz", "br",
+                                        "Wzd", "Wrd", "Whd", "Uzd", "Urd", "Uhd", "bzd", "brd")]
+
+
+P = c_void_p
+# name -> (restype, argtypes); must list every symbol of include/trace_amd.h
+SIGNATURES = {
+    "trace_last_error": (ctypes.c_char_p, []),
+    "trace_abi_version": (c_int, []),
+    "trace_roi_align_fwd_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "trace_roi_align_bwd_f32": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "trace_roi_pool_fwd_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, P, P, P]),
+    "trace_roi_pool_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "trace_roi_align_fwd_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "trace_nms_workspace_bytes": (c_size_t, [c_int]),
+    "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
+    "trace_fpn_levels": (c_int, [P, c_int, c_int, c_int, c_float, c_float, P, P]),
+    "trace_bbox_overlaps": (c_int, [P, c_int, P, c_int, P, P]),
+    "trace_bbox_pair_overlaps": (c_int, [P, P, c_int, P, P]),
+    "trace_relpn_pairs": (c_int, [P, c_int, P, P, P, P]),
+    "trace_clip_to_ndhwc_bf16": (c_int, [P] + [c_int] * 13 + [P, P]),
+    "trace_conv3d_stem_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 11 + [P, P]),
+    "trace_conv3d_igemm_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 13 + [P, c_int, P, P]),
+    "trace_maxpool3d_ndhwc_bf16": (c_int, [P] + [c_int] * 14 + [P, P]),
+    "trace_gemm_bf16_nt": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, P, c_int, P, P]),
+    "trace_transpose_bf16": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "trace_temporal_attention": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
+    "trace_pair_attention_fused": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, c_float, c_int, P, P, P, P]),
+    "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
+                               ctypes.POINTER(TreeGruWeights), P, P, P, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtrace_amd.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "trace_amd: %s is missing - build it with `python -m trace_amd.build` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().trace_last_error()
+        raise RuntimeError("trace_amd %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("trace_amd: tensor must live on a GPU (no CPU path in this library)")

@@ -1,0 +1,399 @@
+// Context-aggregation kernels of the TRACE relation head (gfx950).
+//
+//   temporal attention   lib/combine_tree/cluster_tree3d.py:337-366
+//   fused pair attention lib/modeling_rel/model_builder_rel.py:1524-1612
+//   tree-GRU             lib/combine_tree/cluster_tree.py:163-204, 281-330
+#include "common.h"
+
+namespace trace {
+
+// ---------------------------------------------------------------------------
+// Temporal attention: one workgroup per object/region.
+// ---------------------------------------------------------------------------
+constexpr int TA_MAX_T = 128;
+
+__global__ __launch_bounds__(256) void temporal_attention_kernel(
+    const float* __restrict__ qs, const float* __restrict__ qo, const float* __restrict__ o, int T,
+    int D, int K, float inv_sqrt_d, float* __restrict__ out) {
+  __shared__ float sc[TA_MAX_T];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* q = qs + (long long)n * D;
+  for (int t = wave; t < T; t += 4) {
+    const float* k = qo + ((long long)n * T + t) * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += q[d] * k[d];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) sc[t] = s * inv_sqrt_d;  // cluster_tree3d.py:348
+  }
+  __syncthreads();
+  float mx = -__builtin_inff();
+  for (int t = 0; t < T; ++t) mx = fmaxf(mx, sc[t]);
+  float sum = 0.f;
+  for (int t = 0; t < T; ++t) sum += expf(sc[t] - mx);
+  const float inv = 1.0f / sum;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += (expf(sc[t] - mx) * inv) * o[((long long)n * T + t) * K + k];
+    out[(long long)n * K + k] = acc;  // cluster_tree3d.py:349-350
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused pair attention.  One workgroup per (subject, object) pair:
+//   union box -> adaptive ROIAlign of the K-map and V-map (channels-last bf16,
+//   L2-resident) -> q_s.K / q_o.K per cell -> softmax over the cells -> s_map,
+//   o_map = V * softmax, v_map = V.  The pooled K-map never reaches HBM.
+// A lane owns 8 consecutive channels (16-byte loads); D/8 lanes share a cell.
+// ---------------------------------------------------------------------------
+struct PGeom {
+  int batch;
+  float start_w, start_h, bin_w, bin_h;
+  int grid_h, grid_w;
+};
+
+constexpr int PA_MAX_CELLS = 64;
+
+__global__ __launch_bounds__(256) void pair_attention_kernel(
+    const uint16_t* __restrict__ kmap, const uint16_t* __restrict__ vmap, int B, int H, int W, int D,
+    const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
+    const float* __restrict__ q_s, const float* __restrict__ q_o, float scale, int PS,
+    uint16_t* __restrict__ s_map, uint16_t* __restrict__ o_map, uint16_t* __restrict__ v_map) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc_s = (float*)smem;              // [PA_MAX_CELLS]
+  float* sc_o = sc_s + PA_MAX_CELLS;       // [PA_MAX_CELLS]
+  uint16_t* vbuf = (uint16_t*)(sc_o + PA_MAX_CELLS);  // [cells][D]
+
+  const int p = blockIdx.x;
+  const int cells = PS * PS;
+  const int lpb = D >> 3;           // lanes per cell (power of two, <= 64)
+  const int bpr = 256 / lpb;        // cells per round
+  const int cg = threadIdx.x % lpb; // channel group of this lane
+  const int slot = threadIdx.x / lpb;
+
+  // model_builder_rel.py:1588-1594 union roi; ROIAlign geometry as roi_ops.hip
+  const float* r = rel_rois + (long long)p * 5;
+  PGeom g;
+  g.batch = min(max((int)r[0], 0), B - 1);
+  g.start_w = r[1] * scale;
+  g.start_h = r[2] * scale;
+  {
+    float end_w = r[3] * scale, end_h = r[4] * scale;
+    float roi_w = fmaxf(end_w - g.start_w, 1.0f), roi_h = fmaxf(end_h - g.start_h, 1.0f);
+    g.bin_h = roi_h / (float)PS;
+    g.bin_w = roi_w / (float)PS;
+    g.grid_h = (int)ceilf(roi_h / (float)PS);  // sampling_ratio = 0 (model_builder_rel.py:1343)
+    g.grid_w = (int)ceilf(roi_w / (float)PS);
+  }
+  const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
+  const uint16_t* kimg = kmap + (long long)g.batch * H * W * D + cg * 8;
+  const uint16_t* vimg = vmap + (long long)g.batch * H * W * D + cg * 8;
+
+  float qs[8], qo[8];
+  {
+    const float* a = q_s + (long long)sbj[p] * D + cg * 8;
+    const float* b = q_o + (long long)obj[p] * D + cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qs[j] = a[j];
+      qo[j] = b[j];
+    }
+  }
+
+  for (int cell0 = 0; cell0 < cells; cell0 += bpr) {
+    const int cell = cell0 + slot;
+    const bool live = cell < cells;
+    float ka[8], va[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ka[j] = va[j] = 0.f;
+    if (live) {
+      const int ph = cell / PS, pw = cell - ph * PS;
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        float y = g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          float x = g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          if (y <= 0.f) y = 0.f;
+          if (x <= 0.f) x = 0.f;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          float yy = y, xx = x;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; yy = (float)y_low; } else { y_high = y_low + 1; }
+          if (x_low >= W - 1) { x_high = x_low = W - 1; xx = (float)x_low; } else { x_high = x_low + 1; }
+          float ly = yy - (float)y_low, lx = xx - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+          float w4[4] = {hy * hx, hy * lx, ly * hx, ly * lx};
+          int pos[4] = {y_low * W + x_low, y_low * W + x_high, y_high * W + x_low, y_high * W + x_high};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(kimg + (long long)pos[c] * D);
+            const uint4 vv = *reinterpret_cast<const uint4*>(vimg + (long long)pos[c] * D);
+            const uint32_t* ku = &kv.x;
+            const uint32_t* vu = &vv.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ka[2 * j] += w4[c] * __uint_as_float(ku[j] << 16);
+              ka[2 * j + 1] += w4[c] * __uint_as_float(ku[j] & 0xffff0000u);
+              va[2 * j] += w4[c] * __uint_as_float(vu[j] << 16);
+              va[2 * j + 1] += w4[c] * __uint_as_float(vu[j] & 0xffff0000u);
+            }
+          }
+        }
+      }
+    }
+    float ds = 0.f, dob = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ka[j] *= inv_count;
+      va[j] *= inv_count;
+      ds += qs[j] * ka[j];   // model_builder_rel.py:1606
+      dob += qo[j] * ka[j];
+    }
+    for (int off = lpb >> 1; off > 0; off >>= 1) {
+      ds += __shfl_xor(ds, off);
+      dob += __shfl_xor(dob, off);
+    }
+    if (live) {
+      if (cg == 0) {
+        sc_s[cell] = ds;
+        sc_o[cell] = dob;
+      }
+      uint4 pk;
+      pk.x = pack_bf16x2(va[0], va[1]);
+      pk.y = pack_bf16x2(va[2], va[3]);
+      pk.z = pack_bf16x2(va[4], va[5]);
+      pk.w = pack_bf16x2(va[6], va[7]);
+      *reinterpret_cast<uint4*>(vbuf + (long long)cell * D + cg * 8) = pk;
+    }
+  }
+  __syncthreads();
+  // softmax over the cells (model_builder_rel.py:1607-1609)
+  float ms = -__builtin_inff(), mo = -__builtin_inff();
+  for (int c = 0; c < cells; ++c) {
+    ms = fmaxf(ms, sc_s[c]);
+    mo = fmaxf(mo, sc_o[c]);
+  }
+  float ss = 0.f, so = 0.f;
+  for (int c = 0; c < cells; ++c) {
+    ss += expf(sc_s[c] - ms);
+    so += expf(sc_o[c] - mo);
+  }
+  const float is = 1.0f / ss, io = 1.0f / so;
+  const long long obase = (long long)p * cells * D;
+  for (int idx = threadIdx.x; idx < cells * lpb; idx += blockDim.x) {
+    const int cell = idx / lpb, c8 = idx - cell * lpb;
+    const uint4 pk = *reinterpret_cast<const uint4*>(vbuf + (long long)cell * D + c8 * 8);
+    const float ws = expf(sc_s[cell] - ms) * is, wo = expf(sc_o[cell] - mo) * io;
+    const uint32_t* u = &pk.x;
+    uint4 os, oo;
+    uint32_t* ps = &os.x;
+    uint32_t* po = &oo.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float lo = __uint_as_float(u[j] << 16), hi = __uint_as_float(u[j] & 0xffff0000u);
+      ps[j] = pack_bf16x2(lo * ws, hi * ws);  // model_builder_rel.py:1611
+      po[j] = pack_bf16x2(lo * wo, hi * wo);
+    }
+    const long long o = obase + (long long)cell * D + c8 * 8;
+    *reinterpret_cast<uint4*>(s_map + o) = os;
+    *reinterpret_cast<uint4*>(o_map + o) = oo;
+    *reinterpret_cast<uint4*>(v_map + o) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Tree-GRU: one workgroup per (tree, feature group); levels are walked inside
+// the kernel (a tree is independent of every other tree), so the whole
+// bottom-up + top-down pass of all clips and groups is ONE launch.
+// Weight matrices are passed TRANSPOSED ((in, out) row-major) so that lane j
+// reads consecutive addresses.
+// ---------------------------------------------------------------------------
+struct TreeW {
+  const float *Wz, *Wr, *Wh, *Uz, *Ur, *Uh, *bz, *br;
+  const float *Wzd, *Wrd, *Whd, *Uzd, *Urd, *Uhd, *bzd, *brd;
+};
+struct TreeParams {
+  const float* x;
+  int F, Hd, G;
+  const int32_t *tree_off, *level_off, *n_levels, *parent, *child_off, *child_idx;
+  float *h, *hd, *ws;
+  TreeW w[TRACE_TREE_MAX_GROUPS];
+};
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// dot of column j of a transposed (n_in, Hd) matrix with a strided vector
+__device__ __forceinline__ float dot_col(const float* __restrict__ Wt, int Hd, int j,
+                                         const float* __restrict__ v, int n_in) {
+  float s = 0.f;
+  for (int i = 0; i < n_in; ++i) s += Wt[(long long)i * Hd + j] * v[i];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
+  const int t = blockIdx.x, g = blockIdx.y;
+  const TreeW& w = p.w[g];
+  const int F = p.F, Hd = p.Hd;
+  const long long ldx = (long long)p.G * F, ldh = (long long)p.G * Hd;
+  const float* x = p.x + (long long)g * F;
+  float* h = p.h + (long long)g * Hd;
+  float* hd = p.hd + (long long)g * Hd;
+  float* ws = p.ws + (long long)g * Hd;
+  const int nl = p.n_levels[t];
+  const int32_t* lo = p.level_off + (long long)t * (TRACE_TREE_MAX_LEVELS + 1);
+
+  // ---- bottom-up, leaves (cluster_tree.py:289-292)
+  {
+    const int v0 = lo[0], cnt = (lo[1] - lo[0]) * Hd;
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float* xv = x + v * ldx;
+      float z = sigmoidf_(dot_col(w.Wz, Hd, j, xv, F));
+      float c = tanhf(dot_col(w.Wh, Hd, j, xv, F));
+      h[v * ldh + j] = (1.0f - z) * c;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- bottom-up, inner levels (cluster_tree.py:294-315)
+  for (int l = 1; l < nl; ++l) {
+    const int v0 = lo[l], cnt = (lo[l + 1] - lo[l]) * Hd;
+    // phase A: fa_g[v][j] = sum_c sigmoid(Wr x + Ur h_c + br)[j] * h_c[j]
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float a = dot_col(w.Wr, Hd, j, x + v * ldx, F) + w.br[j];
+      float fa = 0.f;
+      for (int ci = p.child_off[v]; ci < p.child_off[v + 1]; ++ci) {
+        const float* hc = h + (long long)p.child_idx[ci] * ldh;
+        fa += sigmoidf_(a + dot_col(w.Ur, Hd, j, hc, Hd)) * hc[j];
+      }
+      ws[v * ldh + j] = fa;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // phase B: z, candidate, h
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float* xv = x + v * ldx;
+      float az = dot_col(w.Wz, Hd, j, xv, F) + w.bz[j];
+      float hs = 0.f;
+      for (int ci = p.child_off[v]; ci < p.child_off[v + 1]; ++ci) {
+        const float* hc = h + (long long)p.child_idx[ci] * ldh;
+        az += dot_col(w.Uz, Hd, j, hc, Hd);
+        hs += hc[j];
+      }
+      const float z = sigmoidf_(az);
+      const float c = tanhf(dot_col(w.Wh, Hd, j, xv, F) + dot_col(w.Uh, Hd, j, ws + v * ldh, Hd));
+      h[v * ldh + j] = z * hs + (1.0f - z) * c;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  // ---- top-down (cluster_tree.py:189-200, 326-330): roots copy h
+  {
+    const int v0 = lo[nl - 1], cnt = (lo[nl] - lo[nl - 1]) * Hd;
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      hd[v * ldh + j] = h[v * ldh + j];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int l = nl - 2; l >= 0; --l) {
+    const int v0 = lo[l], cnt = (lo[l + 1] - lo[l]) * Hd;
+    // phase A: rh[v][j] = sigmoid(Wrd x + Urd hd_f + brd)[j] * hd_f[j]
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const int f = p.parent[v];
+      const float* hf = hd + (long long)f * ldh;
+      float r = sigmoidf_(dot_col(w.Wrd, Hd, j, x + v * ldx, F) + dot_col(w.Urd, Hd, j, hf, Hd) + w.brd[j]);
+      ws[v * ldh + j] = r * hf[j];
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const int f = p.parent[v];
+      const float* hf = hd + (long long)f * ldh;
+      const float* xv = x + v * ldx;
+      float z = sigmoidf_(dot_col(w.Wzd, Hd, j, xv, F) + dot_col(w.Uzd, Hd, j, hf, Hd) + w.bzd[j]);
+      float c = tanhf(dot_col(w.Whd, Hd, j, xv, F) + dot_col(w.Uhd, Hd, j, ws + v * ldh, Hd));
+      hd[v * ldh + j] = z * hf[j] + (1.0f - z) * c;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+}  // namespace trace
+
+using namespace trace;
+
+extern "C" int trace_temporal_attention(const float* qs, const float* qo, const float* o, int n, int T,
+                                        int D, int K, float inv_sqrt_d, float* out,
+                                        trace_stream_t stream) {
+  TRACE_REQUIRE(n >= 0 && T > 0 && D > 0 && K > 0, "temporal_attention: bad shape");
+  TRACE_REQUIRE(T <= TA_MAX_T, "temporal_attention: T=%d exceeds %d", T, TA_MAX_T);
+  if (n == 0) return 0;
+  TRACE_REQUIRE(qs && qo && o && out, "temporal_attention: null pointer");
+  hipLaunchKernelGGL(temporal_attention_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, qs, qo, o,
+                     T, D, K, inv_sqrt_d, out);
+  return check_launch("temporal_attention");
+}
+
+extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap, int B, int H,
+                                          int W, int D, const float* rel_rois,
+                                          const int32_t* sbj_inds, const int32_t* obj_inds, int P,
+                                          const float* q_s, const float* q_o, float spatial_scale,
+                                          int pooled, uint16_t* s_map, uint16_t* o_map,
+                                          uint16_t* v_map, trace_stream_t stream) {
+  TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_attention: bad shape");
+  TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_attention: D=%d must be 64/128/256/512", D);
+  TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_attention: pooled=%d too large", pooled);
+  if (P == 0) return 0;
+  TRACE_REQUIRE(kmap && vmap && rel_rois && sbj_inds && obj_inds && q_s && q_o && s_map && o_map && v_map,
+                "pair_attention: null pointer");
+  size_t lds = 2 * PA_MAX_CELLS * sizeof(float) + (size_t)pooled * pooled * D * 2;
+  hipLaunchKernelGGL(pair_attention_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, kmap, vmap, B,
+                     H, W, D, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled, s_map,
+                     o_map, v_map);
+  return check_launch("pair_attention_fused");
+}
+
+extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,
+                              const int32_t* tree_off, const int32_t* level_off,
+                              const int32_t* n_levels, const int32_t* parent,
+                              const int32_t* child_off, const int32_t* child_idx,
+                              const trace_tree_gru_weights* weights, float* h, float* hd,
+                              float* workspace, trace_stream_t stream) {
+  TRACE_REQUIRE(n_nodes >= 0 && F > 0 && Hd > 0 && n_groups > 0 && n_trees >= 0, "tree_gru: bad shape");
+  TRACE_REQUIRE(n_groups <= TRACE_TREE_MAX_GROUPS, "tree_gru: more than %d groups", TRACE_TREE_MAX_GROUPS);
+  if (n_trees == 0 || n_nodes == 0) return 0;
+  TRACE_REQUIRE(x && tree_off && level_off && n_levels && parent && child_off && child_idx && weights &&
+                    h && hd && workspace,
+                "tree_gru: null pointer");
+  TreeParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.F = F;
+  p.Hd = Hd;
+  p.G = n_groups;
+  p.tree_off = tree_off;
+  p.level_off = level_off;
+  p.n_levels = n_levels;
+  p.parent = parent;
+  p.child_off = child_off;
+  p.child_idx = child_idx;
+  p.h = h;
+  p.hd = hd;
+  p.ws = workspace;
+  for (int g = 0; g < n_groups; ++g) {
+    const trace_tree_gru_weights& s = weights[g];
+    TRACE_REQUIRE(s.Wz && s.Wr && s.Wh && s.Uz && s.Ur && s.Uh && s.bz && s.br && s.Wzd && s.Wrd &&
+                      s.Whd && s.Uzd && s.Urd && s.Uhd && s.bzd && s.brd,
+                  "tree_gru: null weight pointer in group %d", g);
+    p.w[g] = TreeW{s.Wz, s.Wr, s.Wh, s.Uz, s.Ur, s.Uh, s.bz, s.br,
+                   s.Wzd, s.Wrd, s.Whd, s.Uzd, s.Urd, s.Uhd, s.bzd, s.brd};
+  }
+  hipLaunchKernelGGL(tree_gru_kernel, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("tree_gru");
+}

@@ -1,0 +1,360 @@
+// ROIAlign / ROIPool kernels for gfx950.
+//
+// Reference behaviour: Detectron_pytorch/lib/model/csrc/cuda/ROIAlign_cuda.cu:16-122
+// (forward), :125-254 (backward), cpu/ROIAlign_cpu.cpp:17-219 (arithmetic order
+// of the oracle), cuda/ROIPool_cuda.cu:16-108.
+//
+// This file is compiled with -ffp-contract=off: the f32 NCHW forward reproduces
+// the CPU reference's rounding sequence bit for bit.
+#include "common.h"
+
+namespace trace {
+
+struct RoiGeom {
+  int batch;
+  float start_w, start_h, bin_w, bin_h;
+  int grid_h, grid_w;
+  float count;
+};
+
+// ROIAlign_cuda.cu:78-104 / ROIAlign_cpu.cpp:138-169
+__device__ __forceinline__ RoiGeom roi_geom(const float* r, float scale, int PH, int PW, int sr, int B) {
+  RoiGeom g;
+  // a batch index outside [0,B) is clamped rather than faulting the GPU
+  g.batch = min(max((int)r[0], 0), B - 1);
+  g.start_w = r[1] * scale;
+  g.start_h = r[2] * scale;
+  float end_w = r[3] * scale;
+  float end_h = r[4] * scale;
+  float roi_w = fmaxf(end_w - g.start_w, 1.0f);
+  float roi_h = fmaxf(end_h - g.start_h, 1.0f);
+  g.bin_h = roi_h / (float)PH;
+  g.bin_w = roi_w / (float)PW;
+  g.grid_h = (sr > 0) ? sr : (int)ceilf(roi_h / (float)PH);
+  g.grid_w = (sr > 0) ? sr : (int)ceilf(roi_w / (float)PW);
+  g.count = (float)(g.grid_h * g.grid_w);
+  return g;
+}
+
+struct Bilin {
+  int p1, p2, p3, p4;  // offsets inside one H*W plane (in pixels)
+  float w1, w2, w3, w4;
+  bool valid;
+};
+
+// ROIAlign_cpu.cpp:44-104 / ROIAlign_cuda.cu:22-57
+__device__ __forceinline__ Bilin bilin_setup(float y, float x, int H, int W) {
+  Bilin b;
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) {
+    b.p1 = b.p2 = b.p3 = b.p4 = 0;
+    b.w1 = b.w2 = b.w3 = b.w4 = 0.f;
+    b.valid = false;
+    return b;
+  }
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) {
+    y_high = y_low = H - 1;
+    y = (float)y_low;
+  } else {
+    y_high = y_low + 1;
+  }
+  if (x_low >= W - 1) {
+    x_high = x_low = W - 1;
+    x = (float)x_low;
+  } else {
+    x_high = x_low + 1;
+  }
+  float ly = y - (float)y_low, lx = x - (float)x_low;
+  float hy = 1.0f - ly, hx = 1.0f - lx;
+  b.w1 = hy * hx;
+  b.w2 = hy * lx;
+  b.w3 = ly * hx;
+  b.w4 = ly * lx;
+  b.p1 = y_low * W + x_low;
+  b.p2 = y_low * W + x_high;
+  b.p3 = y_high * W + x_low;
+  b.p4 = y_high * W + x_high;
+  b.valid = true;
+  return b;
+}
+
+__device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int grid) {
+  // roi_start + p * bin + (i + .5f) * bin / grid   (ROIAlign_cpu.cpp:36-42)
+  return start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;
+}
+
+// ---------------------------------------------------------------------------
+// Forward, NCHW f32 (drop-in _C.roi_align_forward semantics).
+// One thread per output element; consecutive lanes write consecutive addresses.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_fwd_f32_kernel(
+    long long nthreads, const float* __restrict__ in, float scale, int B, int C, int H, int W,
+    int PH, int PW, int sr, const float* __restrict__ rois, float* __restrict__ out) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    int pw = (int)(index % PW);
+    int ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
+    const float* plane = in + ((long long)g.batch * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        Bilin b = bilin_setup(y, x, H, W);
+        // ROIAlign_cpu.cpp:204-207 — left-to-right sum, no contraction
+        float v = b.w1 * plane[b.p1] + b.w2 * plane[b.p2] + b.w3 * plane[b.p3] + b.w4 * plane[b.p4];
+        acc += v;
+      }
+    }
+    out[index] = acc / g.count;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward, NCHW f32 (ROIAlign_cuda.cu:177-254).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_bwd_f32_kernel(
+    long long nthreads, const float* __restrict__ grad, float scale, int B, int C, int H, int W,
+    int PH, int PW, int sr, float* __restrict__ gin, const float* __restrict__ rois) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    int pw = (int)(index % PW);
+    int ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
+    float* plane = gin + ((long long)g.batch * C + c) * H * W;
+    float top = grad[index];
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        Bilin b = bilin_setup(y, x, H, W);
+        if (b.valid) {
+          atomicAdd(plane + b.p1, top * b.w1 / g.count);
+          atomicAdd(plane + b.p2, top * b.w2 / g.count);
+          atomicAdd(plane + b.p3, top * b.w3 / g.count);
+          atomicAdd(plane + b.p4, top * b.w4 / g.count);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ROIPool forward/backward (ROIPool_cuda.cu:16-108).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_pool_fwd_f32_kernel(
+    long long nthreads, const float* __restrict__ in, float scale, int B, int C, int H, int W,
+    int PH, int PW, const float* __restrict__ rois, float* __restrict__ out,
+    int32_t* __restrict__ argmax) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    int pw = (int)(index % PW);
+    int ph = (int)((index / PW) % PH);
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    const float* r = rois + (long long)n * 5;
+    int b = min(max((int)r[0], 0), B - 1);
+    int rsw = (int)roundf(r[1] * scale);
+    int rsh = (int)roundf(r[2] * scale);
+    int rew = (int)roundf(r[3] * scale);
+    int reh = (int)roundf(r[4] * scale);
+    int rw = max(rew - rsw + 1, 1);
+    int rh = max(reh - rsh + 1, 1);
+    float bin_h = (float)rh / (float)PH;
+    float bin_w = (float)rw / (float)PW;
+    int hstart = (int)floorf((float)ph * bin_h);
+    int wstart = (int)floorf((float)pw * bin_w);
+    int hend = (int)ceilf((float)(ph + 1) * bin_h);
+    int wend = (int)ceilf((float)(pw + 1) * bin_w);
+    hstart = min(max(hstart + rsh, 0), H);
+    hend = min(max(hend + rsh, 0), H);
+    wstart = min(max(wstart + rsw, 0), W);
+    wend = min(max(wend + rsw, 0), W);
+    bool is_empty = (hend <= hstart) || (wend <= wstart);
+    float maxval = is_empty ? 0.f : -3.402823466e+38f;
+    int maxidx = -1;
+    const float* plane = in + ((long long)b * C + c) * H * W;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) {
+        int bi = h * W + w;
+        float v = plane[bi];
+        if (v > maxval) {
+          maxval = v;
+          maxidx = bi;
+        }
+      }
+    out[index] = maxval;
+    argmax[index] = maxidx;
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_pool_bwd_f32_kernel(
+    long long nthreads, const float* __restrict__ grad, const int32_t* __restrict__ argmax, int B,
+    int C, int H, int W, int PH, int PW, float* __restrict__ gin, const float* __restrict__ rois) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    int c = (int)((index / PW / PH) % C);
+    int n = (int)(index / PW / PH / C);
+    int b = min(max((int)rois[(long long)n * 5], 0), B - 1);
+    int am = argmax[index];
+    if (am != -1) atomicAdd(gin + ((long long)b * C + c) * H * W + am, grad[index]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward, channels-last bf16: input (B,H,W,C), out (K,PH*PW,C).
+// One workgroup per (roi, bin); lane owns 8 consecutive channels (16 B) so each
+// corner read and the output write are 1 KiB-per-wave coalesced accesses; the
+// sample geometry depends only on blockIdx (wave-uniform).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_kernel(
+    const uint16_t* __restrict__ in, int B, int H, int W, int C, const float* __restrict__ rois,
+    float scale, int PH, int PW, int sr, uint16_t* __restrict__ out) {
+  const int bin = blockIdx.x;  // ph*PW+pw
+  const int n = blockIdx.y;
+  const int ph = bin / PW, pw = bin - ph * PW;
+  RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
+  const uint16_t* img = in + (long long)g.batch * H * W * C;
+  uint16_t* dst = out + ((long long)n * PH * PW + bin) * C;
+  const float inv_count = 1.0f / g.count;
+  for (int c0 = threadIdx.x * 8; c0 < C; c0 += blockDim.x * 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        Bilin b = bilin_setup(y, x, H, W);
+        if (!b.valid) continue;
+        uint4 v1 = *reinterpret_cast<const uint4*>(img + (long long)b.p1 * C + c0);
+        uint4 v2 = *reinterpret_cast<const uint4*>(img + (long long)b.p2 * C + c0);
+        uint4 v3 = *reinterpret_cast<const uint4*>(img + (long long)b.p3 * C + c0);
+        uint4 v4 = *reinterpret_cast<const uint4*>(img + (long long)b.p4 * C + c0);
+        const uint32_t* a1 = &v1.x;
+        const uint32_t* a2 = &v2.x;
+        const uint32_t* a3 = &v3.x;
+        const uint32_t* a4 = &v4.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float l = b.w1 * __uint_as_float(a1[j] << 16) + b.w2 * __uint_as_float(a2[j] << 16) +
+                    b.w3 * __uint_as_float(a3[j] << 16) + b.w4 * __uint_as_float(a4[j] << 16);
+          float h = b.w1 * __uint_as_float(a1[j] & 0xffff0000u) +
+                    b.w2 * __uint_as_float(a2[j] & 0xffff0000u) +
+                    b.w3 * __uint_as_float(a3[j] & 0xffff0000u) +
+                    b.w4 * __uint_as_float(a4[j] & 0xffff0000u);
+          acc[2 * j] += l;
+          acc[2 * j + 1] += h;
+        }
+      }
+    }
+    uint4 o;
+    o.x = pack_bf16x2(acc[0] * inv_count, acc[1] * inv_count);
+    o.y = pack_bf16x2(acc[2] * inv_count, acc[3] * inv_count);
+    o.z = pack_bf16x2(acc[4] * inv_count, acc[5] * inv_count);
+    o.w = pack_bf16x2(acc[6] * inv_count, acc[7] * inv_count);
+    *reinterpret_cast<uint4*>(dst + c0) = o;
+  }
+}
+
+static int grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 256LL * 32) b = 256LL * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace trace
+
+using namespace trace;
+
+extern "C" int trace_roi_align_fwd_f32(const float* input, int B, int C, int H, int W,
+                                       const float* rois, int K, float spatial_scale, int pooled_h,
+                                       int pooled_w, int sampling_ratio, float* out,
+                                       trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_align_fwd: bad shape B=%d C=%d H=%d W=%d K=%d", B, C, H, W, K);
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;  // ROIAlign_cuda.cu:278-281
+  TRACE_REQUIRE(input && rois && out, "roi_align_fwd: null pointer");
+  hipLaunchKernelGGL(roi_align_fwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, input, spatial_scale, B, C, H, W, pooled_h, pooled_w, sampling_ratio, rois, out);
+  return check_launch("roi_align_fwd_f32");
+}
+
+extern "C" int trace_roi_align_bwd_f32(const float* grad, const float* rois, int K,
+                                       float spatial_scale, int pooled_h, int pooled_w, int B,
+                                       int C, int H, int W, int sampling_ratio, float* grad_input,
+                                       trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_align_bwd: bad shape");
+  size_t gin_bytes = (size_t)B * C * H * W * sizeof(float);
+  if (gin_bytes) {
+    TRACE_REQUIRE(grad_input, "roi_align_bwd: null grad_input");
+    hipError_t e = hipMemsetAsync(grad_input, 0, gin_bytes, (hipStream_t)stream);
+    TRACE_REQUIRE(e == hipSuccess, "roi_align_bwd: memset: %s", hipGetErrorString(e));
+  }
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;  // ROIAlign_cuda.cu:324-327
+  TRACE_REQUIRE(grad && rois, "roi_align_bwd: null pointer");
+  hipLaunchKernelGGL(roi_align_bwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, grad, spatial_scale, B, C, H, W, pooled_h, pooled_w, sampling_ratio,
+                     grad_input, rois);
+  return check_launch("roi_align_bwd_f32");
+}
+
+extern "C" int trace_roi_pool_fwd_f32(const float* input, int B, int C, int H, int W,
+                                      const float* rois, int K, float spatial_scale, int pooled_h,
+                                      int pooled_w, float* out, int32_t* argmax,
+                                      trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_pool_fwd: bad shape");
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(input && rois && out && argmax, "roi_pool_fwd: null pointer");
+  hipLaunchKernelGGL(roi_pool_fwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, input, spatial_scale, B, C, H, W, pooled_h, pooled_w, rois, out, argmax);
+  return check_launch("roi_pool_fwd_f32");
+}
+
+extern "C" int trace_roi_pool_bwd_f32(const float* grad, const int32_t* argmax, const float* rois,
+                                      int K, int pooled_h, int pooled_w, int B, int C, int H, int W,
+                                      float* grad_input, trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0, "roi_pool_bwd: bad shape");
+  size_t gin_bytes = (size_t)B * C * H * W * sizeof(float);
+  if (gin_bytes) {
+    TRACE_REQUIRE(grad_input, "roi_pool_bwd: null grad_input");
+    hipError_t e = hipMemsetAsync(grad_input, 0, gin_bytes, (hipStream_t)stream);
+    TRACE_REQUIRE(e == hipSuccess, "roi_pool_bwd: memset: %s", hipGetErrorString(e));
+  }
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(grad && argmax && rois, "roi_pool_bwd: null pointer");
+  hipLaunchKernelGGL(roi_pool_bwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, grad, argmax, B, C, H, W, pooled_h, pooled_w, grad_input, rois);
+  return check_launch("roi_pool_bwd_f32");
+}
+
+extern "C" int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H, int W, int C,
+                                             const float* rois, int K, float spatial_scale,
+                                             int pooled_h, int pooled_w, int sampling_ratio,
+                                             uint16_t* out, trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_align_fwd_nhwc: bad shape");
+  TRACE_REQUIRE(C % 8 == 0, "roi_align_fwd_nhwc: C=%d must be a multiple of 8", C);
+  if (K == 0 || C == 0) return 0;
+  TRACE_REQUIRE(K <= 65535, "roi_align_fwd_nhwc: K=%d exceeds 65535 rois per call", K);
+  TRACE_REQUIRE(input && rois && out, "roi_align_fwd_nhwc: null pointer");
+  int threads = C / 8 >= 256 ? 256 : ((C / 8 + 63) / 64) * 64;
+  hipLaunchKernelGGL(roi_align_fwd_nhwc_bf16_kernel, dim3(pooled_h * pooled_w, K), dim3(threads), 0,
+                     (hipStream_t)stream, input, B, H, W, C, rois, spatial_scale, pooled_h, pooled_w,
+                     sampling_ratio, out);
+  return check_launch("roi_align_fwd_nhwc_bf16");
+}
