@@ -1,0 +1,119 @@
+"""GPU parity of the bf16 MFMA implicit-GEMM conv3d / GEMM kernels against a plain
+PyTorch fp32 reference of the same op (run on CPU, on the bf16-rounded operands).
+Tolerance: rtol 2e-2 of the output scale (north_star, bf16 vs fp32)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pack_w(w):
+    # (Cout,Cin,kt,kh,kw) -> (Cout, kt*kh*kw*Cin) tap-major, channel-minor
+    return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def _close(got, ref, tol=2e-2):
+    scale = float(ref.abs().max()) + 1e-6
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+CASES = [
+    # N, Cin, T, H, W, Cout, k, stride, pad, dil
+    (2, 64, 4, 14, 14, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1)),
+    (2, 64, 4, 14, 14, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (1, 64, 2, 9, 11, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),
+    (2, 128, 3, 16, 16, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1)),
+    (1, 256, 2, 16, 16, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1)),
+    (1, 128, 2, 14, 14, 128, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
+    (1, 192, 3, 7, 7, 72, (3, 3, 3), (2, 1, 1), (1, 1, 1), (1, 1, 1)),   # odd sizes, K tail
+    (3, 8, 2, 5, 5, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # tiny
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("fuse", [False, True])
+def test_conv3d_igemm(case, fuse):
+    from trace_amd import ops
+    N, Cin, T, H, W, Cout, k, s, p, d = case
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, Cin, T, H, W), generator=g).bfloat16()
+    w = (torch.randn((Cout, Cin) + k, generator=g) / (Cin * k[0] * k[1] * k[2]) ** 0.5).bfloat16()
+    b = torch.randn((Cout,), generator=g)
+    ref = F.conv3d(x.float(), w.float(), b, stride=s, padding=p, dilation=d)
+    res = None
+    if fuse:
+        res = torch.randn(ref.shape, generator=g).bfloat16()
+        ref = torch.relu(ref + res.float())
+    out = ops.conv3d(x.permute(0, 2, 3, 4, 1).contiguous().to(DEV), _pack_w(w).to(DEV), b.to(DEV), k, s, p, d,
+                     residual=None if res is None else res.permute(0, 2, 3, 4, 1).contiguous().to(DEV), relu=fuse)
+    got = out.float().permute(0, 4, 1, 2, 3).cpu()
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+def test_conv3d_stem_matches_strided_conv():
+    """Stem: 3->64, k(5,7,7), s(2,2,2), p(2,3,3) on the halo-padded clip, incl. the folded
+    temporal stride 4 (= conv stride 2 followed by the pool's frame skipping)."""
+    from trace_amd import ops
+    g = torch.Generator().manual_seed(2)
+    N, T, H, W = 2, 8, 32, 32
+    clip = torch.randn((N, T, 3, H, W), generator=g) * 50
+    w = torch.randn((64, 3, 5, 7, 7), generator=g) * 0.02
+    b = torch.randn((64,), generator=g)
+    xb = clip.bfloat16().float()
+    wb = w.bfloat16().float()
+    ref = torch.relu(F.conv3d(xb.permute(0, 2, 1, 3, 4), wb, b, stride=(2, 2, 2), padding=(2, 3, 3)))
+    # pack: (Cout, kt, kh, kwp=8, Cp=4)
+    wp = torch.zeros((64, 5, 7, 8, 4))
+    wp[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
+    wp = wp.reshape(64, -1).bfloat16().to(DEV)
+    xp = ops.clip_to_ndhwc(clip.to(DEV), True, 4, (2, 2, 3, 3, 3, 5))
+    assert xp.shape == (N, T + 4, H + 6, W + 8, 4)
+    for st in (2, 4):
+        To = (T + 4 - 5) // st + 1
+        out = ops.conv3d_stem(xp, wp, b.to(DEV), 5, 7, 8, (st, 2, 2), (To, 16, 16))
+        got = out.float().permute(0, 4, 1, 2, 3).cpu()
+        _close(got, ref[:, :, ::(st // 2)])
+
+
+@pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024)])
+def test_gemm_nt(shape):
+    from trace_amd import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn((M, K), generator=g).bfloat16()
+    B = (torch.randn((N, K), generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn((N,), generator=g)
+    ref = A.float() @ B.float().t() * 0.5 + bias
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), alpha=0.5, out_f32=True)
+    _close(out.cpu(), ref)
+    out2 = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), alpha=0.5, relu=True)
+    _close(out2.float().cpu(), torch.relu(ref))
+
+
+def test_gemm_nt_batched_and_transpose():
+    from trace_amd import ops
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn((3, 196, 64), generator=g).bfloat16()
+    B = torch.randn((3, 52, 64), generator=g).bfloat16()
+    out = ops.gemm_nt(A.to(DEV), B.to(DEV), alpha=1.0 / 52, out_f32=True)
+    ref = torch.bmm(A.float(), B.float().transpose(1, 2)) / 52
+    _close(out.cpu(), ref)
+    t = ops.transpose(B.to(DEV))
+    assert torch.equal(t.cpu(), B.transpose(1, 2).contiguous())
+
+
+def test_maxpool3d():
+    from trace_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 16, 6, 12, 12), generator=g).bfloat16()
+    xl = x.permute(0, 2, 3, 4, 1).contiguous().to(DEV)
+    for k, s, p in (((1, 3, 3), (2, 2, 2), (0, 1, 1)), ((2, 1, 1), (2, 1, 1), (0, 0, 0)), ((1, 2, 2), (1, 2, 2), (0, 0, 0)),
+                    ((1, 3, 3), (1, 2, 2), (0, 1, 1))):
+        ref = F.max_pool3d(x.float(), k, s, p)
+        got = ops.maxpool3d(xl, k, s, p).float().permute(0, 4, 1, 2, 3).cpu()
+        assert torch.equal(got, ref)

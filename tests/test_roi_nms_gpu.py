@@ -1,0 +1,178 @@
+"""GPU parity: ROIAlign / ROIPool / NMS / box helpers through the C-ABI against
+the CPU oracle (bit-exact for f32 forward / indices) and the golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import synth_boxes, distinct_scores
+from oracle import c_oracle, np_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rois(rng, n, B, k=2.0, size=224.0):
+    return np.concatenate([rng.integers(0, B, (n, 1)).astype(np.float32), synth_boxes(rng, n, k, size)], 1)
+
+
+def test_roi_align_fwd_golden_bitexact(golden):
+    from trace_amd import _C
+    g = golden("roi_align_fwd.npz")
+    feat = torch.from_numpy(g["feat"]).to(DEV)
+    rois = torch.from_numpy(g["rois"]).to(DEV)
+    for sr in (0, 2):
+        for scale in (1.0 / 16, 0.25):
+            out = _C.roi_align_forward(feat, rois, scale, 7, 7, sr).cpu().numpy()
+            assert np.array_equal(out, g["out_sr%d_s%g" % (sr, scale)]), (sr, scale)
+    out = _C.roi_align_forward(feat, rois, 1.0 / 16, 5, 3, 0).cpu().numpy()
+    assert np.array_equal(out, g["out_5x3_sr0"])
+
+
+@pytest.mark.parametrize("sr", [0, 2])
+def test_roi_align_fwd_vs_oracle_bitexact(sr):
+    from trace_amd.roi_layers import ROIAlign
+    rng = np.random.default_rng(11 + sr)
+    x = rng.standard_normal((3, 64, 14, 14)).astype(np.float32)
+    rois = _rois(rng, 50, 3)
+    out = ROIAlign((7, 7), 1 / 16., sr)(torch.from_numpy(x).to(DEV), torch.from_numpy(rois).to(DEV))
+    assert np.array_equal(out.cpu().numpy(), c_oracle.roi_align_fwd(x, rois, 1 / 16., 7, 7, sr))
+
+
+def test_roi_align_empty_and_bwd():
+    from trace_amd.roi_layers import ROIAlign
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((2, 8, 10, 12)).astype(np.float32)).to(DEV)
+    out = ROIAlign((7, 7), 1 / 16., 2)(x, torch.zeros((0, 5), device=DEV))
+    assert tuple(out.shape) == (0, 8, 7, 7)
+    rois = _rois(rng, 9, 2, 1.5, 180.0)
+    for sr in (0, 2):
+        xr = x.clone().requires_grad_(True)
+        y = ROIAlign((7, 7), 1 / 16., sr)(xr, torch.from_numpy(rois).to(DEV))
+        g = torch.from_numpy(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(DEV)
+        y.backward(g)
+        ref = c_oracle.roi_align_bwd(g.cpu().numpy(), rois, 1 / 16., 7, 7, 2, 8, 10, 12, sr)
+        # float atomics: order of adds differs -> tolerance, not bit equality
+        np.testing.assert_allclose(xr.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_roi_pool_fwd_bwd():
+    from trace_amd.roi_layers import ROIPool
+    rng = np.random.default_rng(6)
+    xn = rng.standard_normal((2, 16, 14, 14)).astype(np.float32)
+    rois = _rois(rng, 12, 2)
+    x = torch.from_numpy(xn).to(DEV).requires_grad_(True)
+    y = ROIPool((7, 7), 1 / 16.)(x, torch.from_numpy(rois).to(DEV))
+    out, am = c_oracle.roi_pool_fwd(xn, rois, 1 / 16., 7, 7)
+    assert np.array_equal(y.detach().cpu().numpy(), out)
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    y.backward(torch.from_numpy(g).to(DEV))
+    ref = c_oracle.roi_pool_bwd(g, am, rois, 7, 7, 2, 16, 14, 14)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("sr", [0, 2])
+def test_roi_align_nhwc_bf16(sr):
+    """Channels-last bf16 variant: same sampling rule, bf16 I/O -> rtol 2e-2 (north_star)."""
+    from trace_amd import ops
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 256, 14, 14)).astype(np.float32)
+    xb = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    xr = xb.float().cpu().numpy()  # oracle sees the bf16-rounded input
+    rois = _rois(rng, 33, 2)
+    out = ops.roi_align_nhwc(xb.permute(0, 2, 3, 1).contiguous(), torch.from_numpy(rois).to(DEV), 1 / 16., 7, sr)
+    ref = c_oracle.roi_align_fwd(xr, rois, 1 / 16., 7, 7, sr)
+    got = out.float().permute(0, 3, 1, 2).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2)
+
+
+def test_roi_align_full_size_constant_property():
+    """BASELINE cfg5-sized call (2100 rois x 2048 ch): a constant map pools to the constant."""
+    from trace_amd import _C
+    x = torch.full((8, 2048, 14, 14), 1.5, device=DEV)
+    rng = np.random.default_rng(2)
+    rois = torch.from_numpy(_rois(rng, 2100, 8)).to(DEV)
+    out = _C.roi_align_forward(x, rois, 1 / 16., 7, 7, 0)
+    assert out.shape == (2100, 2048, 7, 7)
+    # inside-the-map boxes: every sample is a convex combination of 1.5 -> within rounding of 1.5
+    assert float((out - 1.5).abs().max()) < 1e-5
+
+
+def test_nms_golden_bitexact(golden):
+    from trace_amd.roi_layers import nms
+    g = golden("nms.npz")
+    names = sorted({k.rsplit("_", 1)[0] for k in g.files})
+    for n in names:
+        keep = nms(torch.from_numpy(g[n + "_boxes"]).to(DEV), torch.from_numpy(g[n + "_scores"]).to(DEV),
+                   float(g[n + "_thresh"]))
+        assert keep.dtype == torch.int64
+        assert np.array_equal(keep.cpu().numpy(), g[n + "_keep"]), n
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129, 300, 1000, 6000])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_nms_vs_oracle(n, mode):
+    from trace_amd import _C
+    rng = np.random.default_rng(100 + n)
+    boxes = synth_boxes(rng, n, 2.0 if n < 2000 else 1.0)
+    scores = distinct_scores(rng, n)
+    thr = 0.7 if n >= 1000 else 0.5
+    keep = _C.nms(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), thr, mode)
+    assert np.array_equal(keep.cpu().numpy(), c_oracle.nms(boxes, scores, thr, mode))
+
+
+def test_nms_ties_and_exact_threshold(golden):
+    from trace_amd import _C
+    g = golden("nms.npz")
+    b = torch.from_numpy(g["eq_boxes"]).to(DEV)
+    s = torch.from_numpy(g["eq_scores"]).to(DEV)
+    assert _C.nms(b, s, 0.5, _C.NMS_GE).tolist() == [0, 2]
+    assert _C.nms(b, s, 0.5, _C.NMS_GT).tolist() == [0, 1, 2]
+    # score ties: documented policy = lower index first (same as the oracle)
+    rng = np.random.default_rng(9)
+    boxes = synth_boxes(rng, 200)
+    scores = (rng.integers(0, 5, 200) / 5.0).astype(np.float32)
+    keep = _C.nms(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), 0.5)
+    assert np.array_equal(keep.cpu().numpy(), c_oracle.nms(boxes, scores, 0.5, 0))
+
+
+def test_nms_idempotent_full_size():
+    """Size-independent property at the RPN size: NMS of the kept set keeps everything."""
+    from trace_amd import _C
+    rng = np.random.default_rng(77)
+    boxes = torch.from_numpy(synth_boxes(rng, 6000, 1.0)).to(DEV)
+    scores = torch.from_numpy(distinct_scores(rng, 6000)).to(DEV)
+    keep = _C.nms(boxes, scores, 0.7)
+    assert 0 < keep.numel() < 6000
+    assert bool((keep[1:] > keep[:-1]).all())
+    again = _C.nms(boxes[keep].contiguous(), scores[keep].contiguous(), 0.7)
+    assert again.numel() == keep.numel()
+
+
+def test_box_helpers_bitexact():
+    from trace_amd import boxes as tb
+    rng = np.random.default_rng(31)
+    b = synth_boxes(rng, 5000, 8.0, 1400.0)
+    b[:50, 2:] = b[:50, :2] - rng.uniform(0, 30, (50, 2)).astype(np.float32)  # degenerate / negative extents
+    exact = np.array([[0, 0, 223, 223], [0, 0, 111, 111], [0, 0, 447, 447], [0, 0, 55, 55], [3, 3, 2, 2]], np.float32)
+    b = np.concatenate([b, exact], 0)
+    lv = tb.map_rois_to_fpn_levels(torch.from_numpy(b).to(DEV), 2, 5).cpu().numpy()
+    assert np.array_equal(lv, np_oracle.map_rois_to_fpn_levels(b.copy(), 2, 5))
+    rois = np.concatenate([np.zeros((len(b), 1), np.float32), b], 1)
+    blobs = tb.add_multilevel_roi_blobs({}, "rois", torch.from_numpy(rois).to(DEV), torch.from_numpy(lv).to(DEV), 2, 5)
+    ref = np_oracle.add_multilevel_roi_blobs({}, "rois", rois, lv, 2, 5)
+    for k in ref:
+        assert np.array_equal(blobs[k].cpu().numpy(), ref[k]), k
+    q = synth_boxes(rng, 37)
+    a = synth_boxes(rng, 211)
+    assert np.array_equal(tb.bbox_overlaps(torch.from_numpy(a).to(DEV), torch.from_numpy(q).to(DEV)).cpu().numpy(),
+                          c_oracle.bbox_overlaps(a, q))
+    a2 = synth_boxes(rng, 211)
+    assert np.array_equal(tb.bbox_pair_overlaps(torch.from_numpy(a).to(DEV), torch.from_numpy(a2).to(DEV)).cpu().numpy(),
+                          c_oracle.bbox_pair_overlaps(a, a2))
+    for n in (1, 2, 20, 100):
+        r = _rois(rng, n, 1)
+        r[:, 0] = 0
+        s, o, rel = tb.relpn_pairs(torch.from_numpy(r).to(DEV))
+        rs, ro, rrel = np_oracle.relpn_pairs(r)
+        assert np.array_equal(s.cpu().numpy(), rs) and np.array_equal(o.cpu().numpy(), ro)
+        assert np.array_equal(rel.cpu().numpy(), rrel.astype(np.float32))

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers of the channels-last bf16 kernels in libtrace_amd.so.
+
+PyTorch is used for device memory and streams only; every op below is one call
+through the C-ABI (include/trace_amd.h).  Tensors must live on the GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+EPI_RELU = 1
+EPI_RESIDUAL = 2
+EPI_OUT_F32 = 4
+
+TREE_MAX_LEVELS = 12
+
+
+def _bf16(t, name="tensor"):
+    L.require_gpu(t)
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError("%s must be bfloat16 (got %s)" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def _f32(t, name="tensor"):
+    L.require_gpu(t)
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s must be float32 (got %s)" % (name, t.dtype))
+    return t.contiguous()
+
+
+def clip_to_ndhwc(x, in_ntchw, Cp, pads=(0, 0, 0, 0, 0, 0)):
+    """f32 (N,C,T,H,W) [or (N,T,C,H,W) if in_ntchw] -> bf16 (N,Tp,Hp,Wp,Cp) with zero halo."""
+    x = _f32(x, "clip")
+    if in_ntchw:
+        N, T, C, H, W = x.shape
+    else:
+        N, C, T, H, W = x.shape
+    pt0, pt1, ph0, ph1, pw0, pw1 = pads
+    out = torch.empty((N, T + pt0 + pt1, H + ph0 + ph1, W + pw0 + pw1, Cp), dtype=torch.bfloat16,
+                      device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_clip_to_ndhwc_bf16(L.ptr(x), N, C, T, H, W, int(bool(in_ntchw)), Cp, pt0,
+                                                 pt1, ph0, ph1, pw0, pw1, L.ptr(out), L.stream()),
+                "clip_to_ndhwc")
+    return out
+
+
+def _out_size(i, k, s, p, d):
+    return (i + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), residual=None,
+           relu=False, out_f32=False):
+    """x (N,T,H,W,Cin) bf16; w (Cout, kt*kh*kw*Cin) bf16 tap-major; bias (Cout) f32 or None."""
+    x = _bf16(x, "x")
+    w = _bf16(w, "w")
+    N, Ti, Hi, Wi, Cin = x.shape
+    Cout = w.shape[0]
+    kt, kh, kw = ksize
+    if w.shape[1] != kt * kh * kw * Cin:
+        raise RuntimeError("weight shape %s does not match taps*Cin=%d" % (tuple(w.shape), kt * kh * kw * Cin))
+    To = _out_size(Ti, kt, stride[0], padding[0], dilation[0])
+    Ho = _out_size(Hi, kh, stride[1], padding[1], dilation[1])
+    Wo = _out_size(Wi, kw, stride[2], padding[2], dilation[2])
+    epi = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    out = torch.empty((N, To, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if residual is not None:
+        residual = _bf16(residual, "residual")
+        if residual.shape != out.shape:
+            raise RuntimeError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(out.shape)))
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_conv3d_igemm_bf16(
+            L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
+            stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
+            L.ptr(residual), epi, L.ptr(out), L.stream()), "conv3d_igemm")
+    return out
+
+
+def conv3d_stem(xp, w, bias, kt, kh, kwp, stride, out_thw, relu=True):
+    """Stem conv on the halo-padded clip xp (N,Tp,Hp,Wp,Cp) bf16; w (Cout, kt*kh*kwp*Cp)."""
+    xp = _bf16(xp, "xp")
+    w = _bf16(w, "w")
+    N, Tp, Hp, Wp, Cp = xp.shape
+    Cout = w.shape[0]
+    To, Ho, Wo = out_thw
+    out = torch.empty((N, To, Ho, Wo, Cout), dtype=torch.bfloat16, device=xp.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(xp.device):
+        L.check(L.lib().trace_conv3d_stem_bf16(L.ptr(xp), N, Tp, Hp, Wp, Cp, L.ptr(w), L.ptr(bias), Cout,
+                                               kt, kh, kwp, stride[0], stride[1], stride[2], To, Ho, Wo,
+                                               EPI_RELU if relu else 0, L.ptr(out), L.stream()),
+                "conv3d_stem")
+    return out
+
+
+def maxpool3d(x, ksize, stride, padding=(0, 0, 0)):
+    x = _bf16(x, "x")
+    N, Ti, Hi, Wi, C = x.shape
+    To = (Ti + 2 * padding[0] - ksize[0]) // stride[0] + 1
+    Ho = (Hi + 2 * padding[1] - ksize[1]) // stride[1] + 1
+    Wo = (Wi + 2 * padding[2] - ksize[2]) // stride[2] + 1
+    out = torch.empty((N, To, Ho, Wo, C), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_maxpool3d_ndhwc_bf16(L.ptr(x), N, Ti, Hi, Wi, C, ksize[0], ksize[1], ksize[2],
+                                                   stride[0], stride[1], stride[2], padding[0], padding[1],
+                                                   padding[2], L.ptr(out), L.stream()), "maxpool3d")
+    return out
+
+
+def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False):
+    """C = alpha * A @ B^T (+bias)(+residual)(+ReLU).  A (M,K) or (b,M,K) bf16; B (N,K) or (b,N,K) bf16."""
+    A = _bf16(A, "A")
+    B = _bf16(B, "B")
+    batched = A.dim() == 3
+    if batched:
+        b, M, K = A.shape
+        if B.dim() == 3:
+            N = B.shape[1]
+            sB = N * K
+        else:
+            N = B.shape[0]
+            sB = 0
+        sA, sC = M * K, M * N
+        out_shape = (b, M, N)
+    else:
+        M, K = A.shape
+        N = B.shape[0]
+        b, sA, sB, sC = 1, 0, 0, 0
+        out_shape = (M, N)
+    if B.shape[-1] != K:
+        raise RuntimeError("gemm_nt: K mismatch %s vs %s" % (tuple(A.shape), tuple(B.shape)))
+    out = torch.empty(out_shape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
+    epi = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    if residual is not None:
+        residual = _bf16(residual, "residual")
+        if residual.shape != out.shape:
+            raise RuntimeError("gemm_nt: residual shape mismatch")
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(A.device):
+        L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, K, K, N, b, sA, sB, sC, float(alpha),
+                                           L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.stream()),
+                "gemm_bf16_nt")
+    return out
+
+
+def transpose(x):
+    """(b, R, C) bf16 -> (b, C, R) bf16 (or 2-D)."""
+    x = _bf16(x, "x")
+    two_d = x.dim() == 2
+    if two_d:
+        x = x.unsqueeze(0)
+    b, R, C = x.shape
+    out = torch.empty((b, C, R), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_transpose_bf16(L.ptr(x), b, R, C, L.ptr(out), L.stream()), "transpose")
+    return out[0] if two_d else out
+
+
+def roi_align_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
+    """x (B,H,W,C) bf16, rois (K,5) f32 -> (K, pooled, pooled, C) bf16."""
+    x = _bf16(x, "x")
+    rois = _f32(rois, "rois")
+    B, H, W, C = x.shape
+    K = rois.shape[0]
+    out = torch.empty((K, pooled, pooled, C), dtype=torch.bfloat16, device=x.device)
+    if K == 0:
+        return out
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_roi_align_fwd_nhwc_bf16(L.ptr(x), B, H, W, C, L.ptr(rois), K,
+                                                      float(spatial_scale), pooled, pooled,
+                                                      int(sampling_ratio), L.ptr(out), L.stream()),
+                "roi_align_nhwc")
+    return out
+
+
+def temporal_attention(qs, qo, o, inv_sqrt_d):
+    """qs (n,D), qo (n,T,D), o (n,T,K) f32 -> (n,K) f32 (cluster_tree3d.py:337-366)."""
+    qs, qo, o = _f32(qs), _f32(qo), _f32(o)
+    n, T, D = qo.shape
+    K = o.shape[2]
+    out = torch.empty((n, K), dtype=torch.float32, device=o.device)
+    with torch.cuda.device(o.device):
+        L.check(L.lib().trace_temporal_attention(L.ptr(qs), L.ptr(qo), L.ptr(o), n, T, D, K,
+                                                 float(inv_sqrt_d), L.ptr(out), L.stream()),
+                "temporal_attention")
+    return out
+
+
+def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled=7):
+    """kmap, vmap (B,H,W,D) bf16; returns s_map, o_map, v_map (P, pooled*pooled, D) bf16."""
+    kmap, vmap = _bf16(kmap, "kmap"), _bf16(vmap, "vmap")
+    rel_rois, q_s, q_o = _f32(rel_rois), _f32(q_s), _f32(q_o)
+    L.require_gpu(sbj_inds, obj_inds)
+    sbj_inds = sbj_inds.to(torch.int32).contiguous()
+    obj_inds = obj_inds.to(torch.int32).contiguous()
+    B, H, W, D = kmap.shape
+    P = rel_rois.shape[0]
+    outs = [torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=kmap.device) for _ in range(3)]
+    with torch.cuda.device(kmap.device):
+        L.check(L.lib().trace_pair_attention_fused(L.ptr(kmap), L.ptr(vmap), B, H, W, D, L.ptr(rel_rois),
+                                                   L.ptr(sbj_inds), L.ptr(obj_inds), P, L.ptr(q_s), L.ptr(q_o),
+                                                   float(spatial_scale), pooled, L.ptr(outs[0]),
+                                                   L.ptr(outs[1]), L.ptr(outs[2]), L.stream()),
+                "pair_attention")
+    return outs
+
+
+def tree_gru(x, F, Hd, n_groups, forest, weights):
+    """x (n_nodes, n_groups*F) f32; forest = dict(tree_off, level_off, n_levels, parent, child_off,
+    child_idx) of int32 device tensors; weights = list (per group) of dicts holding the 16 TRANSPOSED
+    f32 device tensors named as in trace_tree_gru_weights.  Returns h, hd (n_nodes, n_groups*Hd)."""
+    x = _f32(x)
+    n_nodes = x.shape[0]
+    dev = x.device
+    h = torch.empty((n_nodes, n_groups * Hd), dtype=torch.float32, device=dev)
+    hd = torch.empty_like(h)
+    ws = torch.empty_like(h)
+    arr = (L.TreeGruWeights * n_groups)()
+    keep = []
+    for g in range(n_groups):
+        for name, _ in L.TreeGruWeights._fields_:
+            t = _f32(weights[g][name])
+            keep.append(t)
+            setattr(arr[g], name, t.data_ptr())
+    n_trees = forest["tree_off"].numel() - 1
+    with torch.cuda.device(dev):
+        L.check(L.lib().trace_tree_gru(L.ptr(x), n_nodes, F, Hd, n_groups, n_trees, L.ptr(forest["tree_off"]),
+                                       L.ptr(forest["level_off"]), L.ptr(forest["n_levels"]),
+                                       L.ptr(forest["parent"]), L.ptr(forest["child_off"]),
+                                       L.ptr(forest["child_idx"]), arr, L.ptr(h), L.ptr(hd), L.ptr(ws),
+                                       L.stream()), "tree_gru")
+    return h, hd
