@@ -78,6 +78,15 @@ int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H, int W,
                                   int pooled_w, int sampling_ratio,
                                   uint16_t* out, trace_stream_t stream);
 
+/* ROIAlign fused with the AdaptiveAvgPool2d((1,1)) that follows it in
+ * Tail_Layer_3D.map2vec (lib/i3d/box_head3d.py:59-61, I3D_DC5): out (K,C) bf16 =
+ * mean over the pooled_h*pooled_w bins; the (K,PH,PW,C) tensor is never written. */
+int trace_roi_align_avg_nhwc_bf16(const uint16_t* input, int B, int H, int W,
+                                  int C, const float* rois, int K,
+                                  float spatial_scale, int pooled_h,
+                                  int pooled_w, int sampling_ratio,
+                                  uint16_t* out, trace_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* NMS: csrc/nms.h:10-28 (_C.nms), cpu/nms_cpu.cpp:5-65, cuda/nms.cu:23-131, */
 /*      and the run-time path Detectron_pytorch/lib/utils/cython_nms.pyx:37-87 */
@@ -140,6 +149,8 @@ int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
 #define TRACE_EPI_RELU 1     /* ReLU after bias(+residual)                   */
 #define TRACE_EPI_RESIDUAL 2 /* add `residual` (same shape as out) first     */
 #define TRACE_EPI_OUT_F32 4  /* write f32 instead of bf16                    */
+#define TRACE_EPI_LEAKY 8    /* LeakyReLU(0.1) instead of ReLU               */
+#define TRACE_EPI_RES_POST 16 /* add `residual` AFTER the activation          */
 
 /* Conv3d + folded eval-mode BatchNorm3d (+residual)(+ReLU) as an implicit GEMM
  * on bf16 MFMA (mmcv ConvModule at resnet3d.py:250-283,549-557,721-730;
@@ -188,10 +199,12 @@ int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
                        const uint16_t* residual, int epilogue, void* C,
                        trace_stream_t stream);
 
-/* bf16 (rows, cols) -> bf16 (cols, rows) per batch; used to form g^T / phi for
- * the non-local block without leaving channels-last. */
+/* bf16 (rows, cols) -> bf16 (cols, rows) per batch, output row stride ld_out
+ * (>= rows) and batch stride out_batch_stride; used to form g^T for the
+ * non-local block without leaving channels-last. */
 int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int cols,
-                         uint16_t* out, trace_stream_t stream);
+                         uint16_t* out, int ld_out, long long out_batch_stride,
+                         trace_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Context aggregation / relation head                                       */

@@ -33,6 +33,7 @@ SIGNATURES = {
     "trace_roi_pool_fwd_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, P, P, P]),
     "trace_roi_pool_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "trace_roi_align_fwd_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "trace_fpn_levels": (c_int, [P, c_int, c_int, c_int, c_float, c_float, P, P]),
@@ -44,7 +45,7 @@ SIGNATURES = {
     "trace_conv3d_igemm_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 13 + [P, c_int, P, P]),
     "trace_maxpool3d_ndhwc_bf16": (c_int, [P] + [c_int] * 14 + [P, P]),
     "trace_gemm_bf16_nt": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, P, c_int, P, P]),
-    "trace_transpose_bf16": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "trace_transpose_bf16": (c_int, [P, c_int, c_int, c_int, P, c_int, c_longlong, P]),
     "trace_temporal_attention": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
     "trace_pair_attention_fused": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, c_float, c_int, P, P, P, P]),
     "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,

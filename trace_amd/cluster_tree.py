@@ -1,0 +1,142 @@
+"""Hierarchical box tree of the context-aggregation stage.
+
+Host-side restatement of lib/combine_tree/cluster_tree.py `cluster_tree2D.node_cluster`
+(:504-556) with `cluster_algorithm` (:558-593), `get_cluster` (:595-607), `get_distance`
+(:609-615) and `get_new_bbox_feat` (:617-628), plus what `get_A_and_link` (:400-430) and
+`get_lca` (lib/modeling_rel/model_builder_rel.py:1614-1619) derive from it.  The reference
+runs this in numpy on the host too; the MI355X change is what comes OUT of it: instead of
+dense (nodes x nodes) adjacency matrices uploaded 8x per clip (cluster_tree.py:206-215) it
+emits a parent array, CSR child lists and per-level node ranges once per batch of clips
+(the layout trace_tree_gru consumes), and an ancestor table for O(1) LCA lookups.
+
+Arithmetic (float32 distances, exp, argsort/argmin tie behaviour) is kept expression for
+expression so that the tree is the one the reference builds.
+"""
+import math
+
+import numpy as np
+
+MAX_LEVELS = 12  # TRACE_TREE_MAX_LEVELS
+
+
+def _sqdist(x, y):
+    return ((x - y) ** 2).sum(-1)
+
+
+def _cluster_layer(feat, l, r, cluster_num):
+    """One agglomeration layer over nodes l..r -> list of child lists, one per new node."""
+    ids = np.arange(l, r + 1)
+    X, Y = np.meshgrid(ids, ids, indexing='ij')
+    distance = _sqdist(feat[X], feat[Y]).reshape(len(ids), -1)
+    score = -np.sum(np.exp(-distance), axis=1)          # density score (:601)
+    ids = ids[np.argsort(score)]                         # (:602-603)
+    ids = np.hstack((ids[0::2], ids[1::2]))              # even ranks become centres (:604-606)
+    centres, rest = ids[:cluster_num], ids[cluster_num:]
+    children = [[c] for c in centres]
+    if len(rest):
+        rest_flat, cen_flat = np.meshgrid(rest, centres)
+        d = _sqdist(feat[cen_flat.reshape(-1)], feat[rest_flat.reshape(-1)]).reshape(cluster_num, -1)
+        owner = np.argmin(d, axis=0)                     # nearest centre (:584)
+        for i, o in enumerate(owner):
+            children[o].append(rest[i])
+    return children
+
+
+def build_tree(leaf_boxes, max_tree_height=7, partition=2):
+    """leaf_boxes (n,4) float32 -> dict(parent, level_off, boxes, n_leaf) for one clip."""
+    n = leaf_boxes.shape[0]
+    if n <= 0:
+        raise ValueError("a clip needs at least one box")
+    feat = leaf_boxes.copy()
+    parent = [-1] * n
+    level_off = [0, n]
+    cluster_num = int(math.ceil(n))
+    l, r = 0, n - 1
+
+    def add_layer(k):
+        nonlocal feat, l, r
+        groups = _cluster_layer(feat, l, r, k)
+        new = []
+        for gi, sons in enumerate(groups):
+            node = r + 1 + gi
+            for s in sons:
+                parent[s] = node
+            sf = feat[sons]
+            new.append(np.array([sf[:, 0].min(), sf[:, 1].min(), sf[:, 2].max(), sf[:, 3].max()]))
+        parent.extend([-1] * k)
+        feat = np.vstack((feat, np.stack(new, axis=0)))
+        l, r = r + 1, r + k
+        level_off.append(r + 1)
+
+    for _ in range(max_tree_height):
+        cluster_num = int(math.ceil(float(cluster_num) / partition))
+        add_layer(cluster_num)
+        if cluster_num <= 1:
+            break
+    if cluster_num > 1:                                  # force a root (:543-548)
+        add_layer(1)
+    if len(level_off) - 1 > MAX_LEVELS:
+        raise ValueError("tree deeper than %d levels" % MAX_LEVELS)
+    return dict(parent=np.asarray(parent, np.int32), level_off=level_off, boxes=feat, n_leaf=n)
+
+
+def ancestors(tree):
+    """(levels, n_leaf) table: row k = ancestor of each leaf at height k (row 0 = the leaf)."""
+    n = tree["n_leaf"]
+    par = tree["parent"]
+    rows = [np.arange(n)]
+    for _ in range(len(tree["level_off"]) - 2):
+        rows.append(par[rows[-1]])
+    return np.stack(rows, 0)
+
+
+def lca(tree, X, Y):
+    """Lowest common ancestor node id of leaf pairs (model_builder_rel.py:1614-1619)."""
+    anc = ancestors(tree)
+    differ = (anc[:, X] != anc[:, Y]).sum(0)             # ancestors agree from this height on
+    differ = np.minimum(np.maximum(differ, 1), anc.shape[0] - 1)  # X == Y -> parent, as the reference's argmax+1
+    return anc[differ, X]
+
+
+def temporal_hulls(tree, temporal_boxes):
+    """Per-frame hull boxes of the non-leaf nodes (cluster_tree3d.py:368-391): (n,T,4) -> (m,T,4)."""
+    n = tree["n_leaf"]
+    par = tree["parent"]
+    n_tree = par.shape[0]
+    T = temporal_boxes.shape[1]
+    feat = np.zeros((n_tree, T, 4), np.float32)
+    feat[:n] = temporal_boxes
+    lo = tree["level_off"]
+    for k in range(1, len(lo) - 1):
+        for node in range(lo[k], lo[k + 1]):
+            sons = np.nonzero(par == node)[0]
+            sf = feat[sons]
+            feat[node, :, 0] = sf[:, :, 0].min(0)
+            feat[node, :, 1] = sf[:, :, 1].min(0)
+            feat[node, :, 2] = sf[:, :, 2].max(0)
+            feat[node, :, 3] = sf[:, :, 3].max(0)
+    return feat[n:]
+
+
+def forest_arrays(trees):
+    """Concatenate per-clip trees into the int32 arrays trace_tree_gru takes (global node ids)."""
+    tree_off = [0]
+    parent, level_off, n_levels, child_off, child_idx = [], [], [], [0], []
+    for t in trees:
+        base = tree_off[-1]
+        par = t["parent"]
+        nt = par.shape[0]
+        parent.append(np.where(par >= 0, par + base, -1))
+        lo = [base + v for v in t["level_off"]]
+        n_levels.append(len(lo) - 1)
+        level_off.append(lo + [lo[-1]] * (MAX_LEVELS + 1 - len(lo)))
+        order = np.argsort(par, kind="stable")
+        order = order[par[order] >= 0]
+        counts = np.bincount(par[par >= 0], minlength=nt)
+        child_idx.append(order + base)
+        child_off.extend((child_off[-1] + np.cumsum(counts)).tolist())
+        tree_off.append(base + nt)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    return dict(tree_off=i32(tree_off), level_off=i32(level_off).reshape(-1), n_levels=i32(n_levels),
+                parent=i32(np.concatenate(parent)), child_off=i32(child_off),
+                child_idx=i32(np.concatenate(child_idx)) if child_idx else i32([]))

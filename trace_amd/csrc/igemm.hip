@@ -219,6 +219,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
 
   // ---- epilogue: D[row = cout (fq*4+r)][col = position fr]
   const bool relu = p.epi & TRACE_EPI_RELU;
+  const bool leaky = p.epi & TRACE_EPI_LEAKY;
+  const bool res_post = (p.epi & TRACE_EPI_RES_POST) && p.res;
   const bool has_res = (p.epi & TRACE_EPI_RESIDUAL) && p.res;
   const bool out_f32 = p.epi & TRACE_EPI_OUT_F32;
   const long long obase = (long long)blockIdx.z * p.bs_out;
@@ -251,6 +253,17 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
       if (relu) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (leaky) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+      }
+      if (res_post) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
+        v[0] += __uint_as_float(rv.x << 16);
+        v[1] += __uint_as_float(rv.x & 0xffff0000u);
+        v[2] += __uint_as_float(rv.y << 16);
+        v[3] += __uint_as_float(rv.y & 0xffff0000u);
       }
       if (out_f32) {
         *reinterpret_cast<float4*>((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -390,7 +403,8 @@ extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, 
   TRACE_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm: leading dimensions too small");
   TRACE_REQUIRE(batch <= 65535, "gemm: batch too large");
   TRACE_REQUIRE(A && Bm && C, "gemm: null pointer");
-  TRACE_REQUIRE(!(epilogue & TRACE_EPI_RESIDUAL) || residual, "gemm: residual flag without pointer");
+  TRACE_REQUIRE(!(epilogue & (TRACE_EPI_RESIDUAL | TRACE_EPI_RES_POST)) || residual,
+                "gemm: residual flag without pointer");
   TRACE_REQUIRE((((uintptr_t)A | (uintptr_t)Bm | (uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
                 "gemm: pointers must be 16-byte aligned");
   IgemmParams p;

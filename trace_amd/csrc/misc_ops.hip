@@ -85,10 +85,11 @@ __global__ __launch_bounds__(256) void maxpool3d_kernel(const uint16_t* __restri
 
 // (batch, rows, cols) -> (batch, cols, rows), 64x64 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ in, int rows,
-                                                             int cols, uint16_t* __restrict__ out) {
+                                                             int cols, uint16_t* __restrict__ out,
+                                                             int ld_out, long long out_bs) {
   __shared__ uint16_t tile[64][66];
   const uint16_t* src = in + (long long)blockIdx.z * rows * cols;
-  uint16_t* dst = out + (long long)blockIdx.z * rows * cols;
+  uint16_t* dst = out + (long long)blockIdx.z * out_bs;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) dst[(long long)c * rows + r] = tile[tx][i];
+    if (c < cols && r < rows) dst[(long long)c * ld_out + r] = tile[tx][i];
   }
 }
 
@@ -142,12 +143,13 @@ extern "C" int trace_maxpool3d_ndhwc_bf16(const uint16_t* in, int N, int Ti, int
 }
 
 extern "C" int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int cols, uint16_t* out,
-                                    trace_stream_t stream) {
+                                    int ld_out, long long out_batch_stride, trace_stream_t stream) {
   TRACE_REQUIRE(batch >= 0 && rows >= 0 && cols >= 0, "transpose: bad shape");
+  TRACE_REQUIRE(ld_out >= rows && out_batch_stride >= (long long)cols * ld_out, "transpose: bad output strides");
   if (batch == 0 || rows == 0 || cols == 0) return 0;
   TRACE_REQUIRE(batch <= 65535 && ceil_div(rows, 64) <= 65535, "transpose: grid too large");
   TRACE_REQUIRE(in && out, "transpose: null pointer");
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64), batch),
-                     dim3(256), 0, (hipStream_t)stream, in, rows, cols, out);
+                     dim3(256), 0, (hipStream_t)stream, in, rows, cols, out, ld_out, out_batch_stride);
   return check_launch("transpose_bf16");
 }

@@ -264,6 +264,58 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// ROIAlign + AdaptiveAvgPool2d((1,1)) fused (Tail_Layer_3D.map2vec with I3D_DC5,
+// lib/i3d/box_head3d.py:59-61): out (K,C) bf16 = mean over the PH*PW bins of the
+// ROIAlign output, without writing the (K,PH,PW,C) tensor.  One workgroup per roi.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(
+    const uint16_t* __restrict__ in, int B, int H, int W, int C, const float* __restrict__ rois,
+    float scale, int PH, int PW, int sr, uint16_t* __restrict__ out) {
+  const int n = blockIdx.x;
+  RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
+  const uint16_t* img = in + (long long)g.batch * H * W * C;
+  const float norm = 1.0f / (g.count * (float)(PH * PW));
+  for (int c0 = threadIdx.x * 8; c0 < C; c0 += blockDim.x * 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ph = 0; ph < PH; ++ph)
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
+        for (int pw = 0; pw < PW; ++pw)
+          for (int ix = 0; ix < g.grid_w; ++ix) {
+            float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
+            Bilin b = bilin_setup(y, x, H, W);
+            if (!b.valid) continue;
+            uint4 v1 = *reinterpret_cast<const uint4*>(img + (long long)b.p1 * C + c0);
+            uint4 v2 = *reinterpret_cast<const uint4*>(img + (long long)b.p2 * C + c0);
+            uint4 v3 = *reinterpret_cast<const uint4*>(img + (long long)b.p3 * C + c0);
+            uint4 v4 = *reinterpret_cast<const uint4*>(img + (long long)b.p4 * C + c0);
+            const uint32_t* a1 = &v1.x;
+            const uint32_t* a2 = &v2.x;
+            const uint32_t* a3 = &v3.x;
+            const uint32_t* a4 = &v4.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[2 * j] += b.w1 * __uint_as_float(a1[j] << 16) + b.w2 * __uint_as_float(a2[j] << 16) +
+                            b.w3 * __uint_as_float(a3[j] << 16) + b.w4 * __uint_as_float(a4[j] << 16);
+              acc[2 * j + 1] += b.w1 * __uint_as_float(a1[j] & 0xffff0000u) +
+                                b.w2 * __uint_as_float(a2[j] & 0xffff0000u) +
+                                b.w3 * __uint_as_float(a3[j] & 0xffff0000u) +
+                                b.w4 * __uint_as_float(a4[j] & 0xffff0000u);
+            }
+          }
+      }
+    uint4 o;
+    o.x = pack_bf16x2(acc[0] * norm, acc[1] * norm);
+    o.y = pack_bf16x2(acc[2] * norm, acc[3] * norm);
+    o.z = pack_bf16x2(acc[4] * norm, acc[5] * norm);
+    o.w = pack_bf16x2(acc[6] * norm, acc[7] * norm);
+    *reinterpret_cast<uint4*>(out + (long long)n * C + c0) = o;
+  }
+}
+
 static int grid_for(long long n) {
   long long b = (n + 255) / 256;
   if (b > 256LL * 32) b = 256LL * 32;
@@ -357,4 +409,19 @@ extern "C" int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H
                      (hipStream_t)stream, input, B, H, W, C, rois, spatial_scale, pooled_h, pooled_w,
                      sampling_ratio, out);
   return check_launch("roi_align_fwd_nhwc_bf16");
+}
+
+extern "C" int trace_roi_align_avg_nhwc_bf16(const uint16_t* input, int B, int H, int W, int C,
+                                             const float* rois, int K, float spatial_scale,
+                                             int pooled_h, int pooled_w, int sampling_ratio,
+                                             uint16_t* out, trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_align_avg_nhwc: bad shape");
+  TRACE_REQUIRE(C % 8 == 0, "roi_align_avg_nhwc: C=%d must be a multiple of 8", C);
+  if (K == 0 || C == 0) return 0;
+  TRACE_REQUIRE(input && rois && out, "roi_align_avg_nhwc: null pointer");
+  int threads = C / 8 >= 256 ? 256 : ((C / 8 + 63) / 64) * 64;
+  hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(K), dim3(threads), 0, (hipStream_t)stream,
+                     input, B, H, W, C, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, out);
+  return check_launch("roi_align_avg_nhwc_bf16");
 }

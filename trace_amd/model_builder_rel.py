@@ -1,0 +1,422 @@
+"""TRACE relation model on MI355X — the per-clip hot path of
+lib/modeling_rel/model_builder_rel.py `Generalized_RCNN` (:107-360 modules, :664-1204 forward,
+inference / pre-computed-box flow) with lib/combine_tree/cluster_tree3d.py:114-366.
+
+Same sub-module names and parameter shapes as the reference (Box_Head, Box_Outs, cem_Box_Outs,
+S_Head, O_Head, Prd_RCNN, cluster_tree3d, embed_*, spatio_*, sem_*, relation_infer_*,
+freq_bias.rel_baseline) so its checkpoints load.  The two 2-D conv bodies (Conv_Body,
+Prd_RCNN2D) and the RPN are "next" rows of SURVEY.md 8(f): their outputs `blob_conv` /
+`feat_map` are inputs here.
+
+MI355X-first differences from the reference's control flow (results are the same):
+  * B clips are processed together (the reference is 1 clip per GPU call): one I3D pass, one
+    ROIAlign per feature map, one GEMM per layer over all clips' rois / pairs;
+  * activations are channels-last bf16, every Linear / 1x1 conv is the bf16 MFMA GEMM of
+    libtrace_amd.so, ROIAlign / temporal attention / pair attention / tree-GRU are HIP kernels;
+  * Box_Head, S_Head and O_Head pool the SAME rois from the SAME map (:938,:949-950): pooled once,
+    the three fc1 run as one GEMM; `Box_Head(use_relu=True)` + Box_Outs (:742-743) equals
+    Box_Outs(relu(Box_Head(use_relu=False))) (:938-939) on the pre-computed rois: computed once;
+  * the box tree is built on the host (as in the reference) while the I3D kernels run; it is
+    uploaded once as parent / CSR arrays instead of 8 dense adjacency matrices per clip.
+Small elementwise glue (softmax over 36 classes, LayerNorm(256), gathers, sigmoid) is torch on
+the GPU; it is listed in DESIGN.md.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import cluster_tree as ct
+from . import ops
+from .config import TraceConfig, vidvrd_config
+from .heads import (cluster_tree3d, fast_rcnn_outputs, init_msra_conv, init_xavier, roi_2mlp_head,
+                    xavier_fill)
+from .resnet3d import ResNet3d, i3d_dc5_config
+
+
+class FrequencyBias(nn.Module):
+    """lib/modeling_rel/sparse_targets_rel.py:23-72 (table supplied by the caller / checkpoint)."""
+
+    def __init__(self, num_objs, num_prd):
+        super().__init__()
+        self.num_objs = num_objs
+        self.rel_baseline = nn.Embedding(num_objs * num_objs, num_prd)
+
+    def rel_index_with_labels(self, labels):
+        return self.rel_baseline(labels[:, 0] * self.num_objs + labels[:, 1])
+
+
+def _bf(x):
+    return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
+
+
+class Generalized_RCNN(nn.Module):
+    def __init__(self, cfg: TraceConfig = None):
+        super().__init__()
+        cfg = cfg or vidvrd_config()
+        self.cfg = cfg
+        C = cfg.CONV_BODY_DIM
+        D = cfg.MLP_HEAD_DIM
+        low = cfg.LOW_FEAT_DIM
+        n_rel = cfg.NUM_PRD_CLASSES                      # MULTI_RELATION (:157-158)
+        infer = D // cfg.RESIZE_HIDDEN_DIM
+        fc = D // cfg.RESIZE_HIDDEN_DIM
+        E = cfg.OBJ_EMBED_DIM
+        ncls = cfg.NUM_CLASSES
+        self.pool_size = cfg.ROI_XFORM_RESOLUTION
+        self.Box_Head = roi_2mlp_head(C, cfg)
+        self.Box_Outs = fast_rcnn_outputs(D, cfg)
+        self.Prd_RCNN = ResNet3d(**i3d_dc5_config())      # :166-183
+        self.cluster_tree3d = cluster_tree3d(self.Prd_RCNN.feat_dim, cfg)   # :238-251
+        self.embed_obj_det = nn.Linear(ncls, E, bias=False)
+        self.embed_s = nn.Linear(ncls, E, bias=False)
+        self.embed_o = nn.Linear(ncls, E, bias=False)
+        self.after_obj_det_embed = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(E, D))
+        self.restore_obj_feat = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(fc, D, bias=True))
+        self.spatio_atten_s = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(D, low, bias=True))
+        self.spatio_atten_o = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(D, low, bias=True))
+        self.spatio_atten_map = nn.Conv2d(self.Prd_RCNN.feat_dim, low, 1, bias=True)
+        self.atten_q_map = nn.Conv2d(self.Prd_RCNN.feat_dim, low, 1, bias=True)
+        self.spatio_inferA = nn.Sequential(nn.Conv2d(low, low, 1, bias=True))
+        self.spatio_inferB = nn.Sequential(nn.Conv2d(low, low, 1, bias=True))
+        self.spatio_infer_fc = nn.Sequential(nn.Linear(low * self.pool_size ** 2, infer, bias=True))
+        self.sem_s = nn.Sequential(nn.Linear(D, n_rel, bias=True))
+        self.sem_s_e = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(E, infer, bias=True))
+        self.sem_o = nn.Sequential(nn.Linear(D, n_rel, bias=True))
+        self.sem_o_e = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(E, infer, bias=True))
+        self.sem_r = nn.Sequential(nn.LeakyReLU(0.1), nn.Linear(fc, infer, bias=True))
+        self.relation_infer_sem = nn.Sequential(nn.Dropout(p=0.5), nn.LeakyReLU(0.1, inplace=True),
+                                                nn.Linear(infer, n_rel, bias=True))
+        self.relation_infer_spa = nn.Sequential(nn.Dropout(p=0.5), nn.LeakyReLU(0.1, inplace=True),
+                                                nn.Linear(infer, n_rel, bias=True))
+        self.freq_bias = FrequencyBias(ncls - 1, n_rel)
+        # :362-391 reset()
+        for m in (self.after_obj_det_embed, self.restore_obj_feat, self.spatio_atten_s, self.spatio_atten_o,
+                  self.spatio_infer_fc, self.sem_s, self.sem_s_e, self.sem_o, self.sem_o_e, self.sem_r,
+                  self.relation_infer_sem, self.relation_infer_spa):
+            m.apply(init_xavier)
+        init_xavier(self.spatio_atten_map)
+        init_xavier(self.atten_q_map)
+        self.spatio_inferA.apply(init_msra_conv)
+        self.spatio_inferB.apply(init_msra_conv)
+        # :349-350, :419-420
+        import copy
+        self.S_Head = copy.deepcopy(self.Box_Head)
+        self.O_Head = copy.deepcopy(self.S_Head)
+        self.cem_Box_Outs = fast_rcnn_outputs(D, cfg, with_bbox=False)
+        self.cem_Box_Outs.load_state_dict({k: v for k, v in self.Box_Outs.state_dict().items() if "cls_score" in k})
+        self._pk = {}
+
+    # ------------------------------------------------------------------ packed-weight cache
+    def _apply(self, fn, *a, **k):
+        self._pk = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._pk = {}
+        return super().load_state_dict(*a, **k)
+
+    def _cached(self, key, make):
+        v = self._pk.get(key)
+        if v is None:
+            with torch.no_grad():
+                v = make()
+            self._pk[key] = v
+        return v
+
+    @staticmethod
+    def _pad_k(w, mult=8):
+        k = w.shape[1]
+        if k % mult:
+            w = F.pad(w, (0, mult - k % mult))
+        return w
+
+    @staticmethod
+    def _pad_n(w, b, mult=8):
+        n = w.shape[0]
+        if n % mult:
+            w = F.pad(w, (0, 0, 0, mult - n % mult))
+            if b is not None:
+                b = F.pad(b, (0, mult - n % mult))
+        return w, b
+
+    def _lin_w(self, key, layers, perm_hw_c=None):
+        """Packed (W bf16 (Np,Kp), bias f32 (Np) | None, N) of one Linear / 1x1 conv or several
+        stacked along the output dimension."""
+        def make():
+            ws, bs = [], []
+            for l in layers:
+                w = l.weight.detach().float().reshape(l.weight.shape[0], -1)
+                if perm_hw_c is not None:  # columns (C, ph, pw) -> (ph, pw, C): channels-last pooled rows
+                    c, hw = perm_hw_c
+                    w = w.view(w.shape[0], c, hw).permute(0, 2, 1).reshape(w.shape[0], -1)
+                ws.append(w)
+                bs.append(l.bias.detach().float() if l.bias is not None else torch.zeros(w.shape[0], device=w.device))
+            w = torch.cat(ws, 0)
+            b = torch.cat(bs, 0) if any(l.bias is not None for l in layers) else None
+            n = w.shape[0]
+            w, b = self._pad_n(self._pad_k(w), b)
+            return w.to(torch.bfloat16).contiguous(), (b.contiguous() if b is not None else None), n
+        return self._cached(key, make)
+
+    def _gemm(self, x, key, layers, perm_hw_c=None, **kw):
+        """x (M,K) -> (M,N) through the bf16 MFMA GEMM; pads K / slices N as needed."""
+        w, b, n = self._lin_w(key, layers, perm_hw_c)
+        x = _bf(x)
+        if x.shape[-1] != w.shape[1]:
+            x = F.pad(x, (0, w.shape[1] - x.shape[-1]))
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        y = ops.gemm_nt(x, w, bias=b, **kw)
+        return y if y.shape[-1] == n else y[..., :n]
+
+    def _tree_weights(self):
+        def make():
+            out = []
+            for tm in self.cluster_tree3d.tree_message_passing_list:
+                d = {}
+                for sfx in ("", "d"):
+                    for n in ("Wz", "Wr", "Wh", "Uz", "Ur", "Uh"):
+                        d[n + sfx] = getattr(tm, n + sfx)[0].weight.detach().float().t().contiguous()
+                    d["bz" + sfx] = getattr(tm, "Uz" + sfx)[0].bias.detach().float().contiguous()
+                    d["br" + sfx] = getattr(tm, "Ur" + sfx)[0].bias.detach().float().contiguous()
+                out.append(d)
+            return out
+        return self._cached("tree", make)
+
+    def _ffn12_w(self):
+        """Per group (FFN1 | FFN2) stacked along K with bias b1+b2 (cluster_tree.py:203)."""
+        def make():
+            out = []
+            for tm in self.cluster_tree3d.tree_message_passing_list:
+                w = torch.cat([tm.FFN1[0].weight.detach().float(), tm.FFN2[0].weight.detach().float()], 1)
+                b = tm.FFN1[0].bias.detach().float() + tm.FFN2[0].bias.detach().float()
+                out.append((w.to(torch.bfloat16).contiguous(), b.contiguous()))
+            return out
+        return self._cached("ffn12", make)
+
+    # ------------------------------------------------------------------ host-side roi lists
+    @staticmethod
+    def _temporal_roi_list(boxes, T, frame0):
+        """Temporal ROIAlign list of one clip in OBJECT-major output order (j, t).  The reference pairs
+        frame t with the box of object (t*n + j) // T (cluster_tree3d.py:158-162 builds an object-major
+        box list against frame-major ids, :181-182 views the result (T, n)); reproduced exactly."""
+        n = boxes.shape[0]
+        j, t = np.meshgrid(np.arange(n), np.arange(T), indexing="ij")
+        src = (t * n + j) // T
+        rois = np.empty((n, T, 5), np.float32)
+        rois[:, :, 0] = frame0 + t
+        rois[:, :, 1:] = boxes[src]
+        return rois.reshape(-1, 5)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1):
+        """Inference on B clips.
+          all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688)
+          blob_conv  (B,2048,H/16,W/16) f32 NCHW or (B,H/16,W/16,2048) bf16 — Conv_Body(data) (:702)
+          feat_map   same layouts — Prd_RCNN2D(cur frame) (:1006-1007)
+          det_rois   list of B numpy (n_b,5) [*,x1,y1,x2,y2] key-frame rois (:894)
+        Returns a list of B dicts with the reference's return keys (:1162-1182)."""
+        if self.training:
+            raise ValueError('You should call this function only on inference. '
+                             'Set the network in inference mode by net.eval().')
+        with torch.no_grad():
+            return self._forward(all_frames, blob_conv, feat_map, det_rois, im_scale, f_scale, topk, prd_k)
+
+    @staticmethod
+    def _nhwc(x):
+        if x.dtype == torch.bfloat16 and x.shape[-1] >= x.shape[1]:
+            return x.contiguous()
+        return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+
+    def _forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale, f_scale, topk, prd_k):
+        cfg = self.cfg
+        dev = all_frames.device
+        B = all_frames.shape[0]
+        ps = self.pool_size
+        D, low = cfg.MLP_HEAD_DIM, cfg.LOW_FEAT_DIM
+        C = cfg.CONV_BODY_DIM
+        ct3 = self.cluster_tree3d
+        # ---- I3D backbone: launched first, the host work below overlaps it (:978-981)
+        tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True)          # (B,T',h,w,2048) bf16
+        Tn = tmaps.shape[1]
+        tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
+        blob = self._nhwc(blob_conv)
+        fmap = self._nhwc(feat_map)
+
+        # ---- host: roi lists, box trees, pair lists (numpy, as in the reference)
+        n_list = [int(r.shape[0]) for r in det_rois]
+        off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int64)
+        Ntot = int(off[-1])
+        det_all = np.concatenate([np.concatenate([np.full((r.shape[0], 1), b, np.float32),
+                                                  np.asarray(r[:, 1:5], np.float32)], 1)
+                                  for b, r in enumerate(det_rois)], 0)
+        scale3d = float(1.0 * f_scale * (1.0 / im_scale))                        # :1766-1770
+        trees, t_obj, t_reg, reg_rois, pairs = [], [], [], [], []
+        m_list = []
+        for b in range(B):
+            roi = det_all[off[b]:off[b + 1]].copy()
+            roi[:, 1:5] *= scale3d
+            boxes = roi[:, 1:5].astype(np.float32)
+            tree = ct.build_tree(boxes, cfg.MSP_MAX_TREE_HEIGHT, cfg.CLUSTER_NUM_PARTITION)
+            trees.append(tree)
+            n = n_list[b]
+            m = tree["parent"].shape[0] - n
+            m_list.append(m)
+            t_obj.append(self._temporal_roi_list(boxes, Tn, b * Tn))
+            hull = ct.temporal_hulls(tree, np.repeat(boxes[:, None, :], Tn, axis=1))     # (m,T,4)
+            flat = hull.reshape(-1, 4)                                                   # object-major list
+            jj, tt = np.meshgrid(np.arange(m), np.arange(Tn), indexing="ij")
+            rr = np.empty((m, Tn, 5), np.float32)
+            rr[:, :, 0] = b * Tn + tt
+            rr[:, :, 1:] = flat[tt * m + jj]                                             # same quirk as objects
+            t_reg.append(rr.reshape(-1, 5))
+            reg_rois.append(np.concatenate([np.full((m, 1), b, np.float32), tree["boxes"][n:].astype(np.float32)], 1))
+            if n > 1:
+                s = np.repeat(np.arange(n), n - 1)
+                o = np.tile(np.arange(n - 1), n)
+                o = o + (o >= s)
+            else:
+                s = o = np.zeros(1, np.int64)
+            union = np.stack([np.full(len(s), b, np.float32), np.minimum(roi[s, 1], roi[o, 1]),
+                              np.minimum(roi[s, 2], roi[o, 2]), np.maximum(roi[s, 3], roi[o, 3]),
+                              np.maximum(roi[s, 4], roi[o, 4])], 1).astype(np.float32)
+            pairs.append((s, o, ct.lca(tree, s, o) - n, union))
+        moff = np.concatenate([[0], np.cumsum(m_list)]).astype(np.int64)
+        Mtot = int(moff[-1])
+        forest = {k: torch.from_numpy(v).to(dev) for k, v in ct.forest_arrays(trees).items()}
+        node_obj = np.concatenate([np.arange(n_list[b]) + off[b] + moff[b] for b in range(B)])
+        node_reg = np.concatenate([np.arange(m_list[b]) + off[b + 1] + moff[b] for b in range(B)])
+        up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        det_all_d = up(det_all)
+        node_obj_d, node_reg_d = up(node_obj), up(node_reg)
+        X = up(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]))
+        Y = up(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]))
+        LCA = up(np.concatenate([p[2] + moff[b] for b, p in enumerate(pairs)]))
+        union_d = up(np.concatenate([p[3] for p in pairs], 0))
+        poff = np.concatenate([[0], np.cumsum([len(p[0]) for p in pairs])]).astype(np.int64)
+
+        # ---- detection heads on the key frame (:742-743, :938-952)
+        pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
+        pooled = pooled.view(Ntot, ps * ps * C)
+        h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True)
+        ori = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True)
+        det_s = self._gemm(h1[:, D:2 * D], "s_fc2", [self.S_Head.fc2], out_f32=True)   # NO_FC7_RELU
+        det_o = self._gemm(h1[:, 2 * D:], "o_fc2", [self.O_Head.fc2], out_f32=True)
+        if not cfg.NO_FC7_RELU:
+            det_s, det_o = F.relu(det_s), F.relu(det_o)
+        cls = F.softmax(self._gemm(F.relu(ori), "cls", [self.Box_Outs.cls_score], out_f32=True), dim=1)
+        det_scores, det_labels = cls[:, 1:].max(dim=1)                           # :903-904
+        det_labels = det_labels + 1
+        emb = self._gemm(cls, "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], out_f32=True, leaky=True)
+        E = cfg.OBJ_EMBED_DIM
+        det_feat = ori + self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True)  # :945-946
+
+        # ---- cluster_tree3d: temporal object features (:158-201)
+        def temporal_branch(roi_list, cur_feat, fc, q_s_l, q_o_l, val, tag):
+            rois_d = up(np.concatenate(roi_list, 0))
+            tvec = ops.roi_align_avg_nhwc(tm_flat, rois_d, cfg.REL_SPATIAL_SCALE, ps, 0)  # ROIAlign + box_head3d.py:60-61
+            tfeat = self._gemm(tvec, tag + "_fc2", [fc.fc2], relu=True, out_f32=True)    # (K,D), (obj,t) order
+            k = cur_feat.shape[0]
+            qs = self._gemm(cur_feat, tag + "_qs", [q_s_l[0]], out_f32=True)
+            qo = self._gemm(tfeat, tag + "_qo", [q_o_l[0]], out_f32=True)
+            att = ops.temporal_attention(qs, qo.view(k, Tn, low), tfeat.view(k, Tn, D), 1.0 / math.sqrt(low))
+            v = self._gemm(att, tag + "_v0", [val[0]], out_f32=True)
+            v = F.relu(F.layer_norm(v, (v.shape[-1],), val[1].weight, val[1].bias, val[1].eps))
+            return cur_feat + self._gemm(v, tag + "_v3", [val[3]], out_f32=True)
+
+        obj_agg = temporal_branch(t_obj, det_feat, ct3.temporal_obj_fc, ct3.temporal_obj_atten_q_s,
+                                  ct3.temporal_obj_atten_q_o, ct3.temporal_obj_feat_val, "tobj")
+        # ---- regions (:222-305)
+        reg_rois_d = up(np.concatenate(reg_rois, 0))
+        reg_map = ops.roi_align_nhwc(fmap, reg_rois_d, cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
+        r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
+        reg_feat = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True)
+        reg_agg = temporal_branch(t_reg, reg_feat, ct3.temporal_r_fc, ct3.temporal_r_atten_q_s,
+                                  ct3.temporal_r_atten_q_o, ct3.temporal_r_feat_val, "treg")
+        # ---- tree message passing (:307-330)
+        o2c = self._gemm(F.relu(obj_agg), "o2c", [ct3.o2c[1]], out_f32=True)
+        r2c = self._gemm(F.relu(reg_agg), "r2c", [ct3.r2c[1]], out_f32=True)
+        fc = ct3.feat_combine
+        G = ct3.group_coeffi
+        gw = fc // G
+        x_nodes = torch.empty((Ntot + Mtot, fc), dtype=torch.float32, device=dev)
+        x_nodes[node_obj_d] = o2c
+        x_nodes[node_reg_d] = r2c
+        h, hd = ops.tree_gru(x_nodes, gw, gw, G, forest, self._tree_weights())
+        hcat = torch.cat([h.view(-1, G, gw), hd.view(-1, G, gw)], 2).to(torch.bfloat16)   # (nodes, G, 2*gw)
+        agg = torch.empty((Ntot + Mtot, fc), dtype=torch.bfloat16, device=dev)
+        for g, (w12, b12) in enumerate(self._ffn12_w()):
+            ops.gemm_nt(hcat[:, g, :], w12, bias=b12, relu=True, out=agg[:, g * gw:(g + 1) * gw])   # FFN1(h)+FFN2(hd), ReLU of :387
+        pf = self._gemm(agg, "ct_ffn", [ct3.FFN[1]], leaky=True)                 # leaky: only consumers are :273-275, :310-312
+        pf_obj, pf_reg = pf[node_obj_d], pf[node_reg_d]
+        # ---- back in _forward (:1018-1024)
+        obj_feature = det_feat + self._gemm(pf_obj, "restore", [self.restore_obj_feat[1]], out_f32=True)
+        obj_score = F.softmax(self._gemm(F.relu(obj_feature), "cem_cls", [self.cem_Box_Outs.cls_score], out_f32=True), dim=1)
+        # ---- target-adaptive pair attention (:1524-1612)
+        lo = F.leaky_relu(obj_feature, 0.1)
+        q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
+        q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
+        fm2 = fmap.view(-1, fmap.shape[-1])
+        kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+        vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+        s_map, o_map, v_map = ops.pair_attention(kmap, vmap, union_d, X, Y, q_s.contiguous(), q_o.contiguous(),
+                                                 cfg.REL_SPATIAL_SCALE, ps)
+        P = union_d.shape[0]
+        so = torch.cat([s_map, o_map], 2).view(P * ps * ps, 2 * low)
+        wab, bab, _ = self._cached("inferAB", lambda: (
+            torch.cat([self.spatio_inferA[0].weight.detach().float().view(low, low),
+                       self.spatio_inferB[0].weight.detach().float().view(low, low)], 1).to(torch.bfloat16).contiguous(),
+            (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low))
+        sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
+        spatio_infer = self._gemm(sp.view(P, ps * ps * low), "sp_fc", [self.spatio_infer_fc[0]], (low, ps * ps), leaky=True)  # :1042 (+ leaky of :329)
+        logit_spa = self._gemm(spatio_infer, "rel_spa", [self.relation_infer_spa[2]], out_f32=True)
+        # ---- semantic branch (:1643-1668)
+        low_s = self._gemm(emb[:, E:2 * E], "sem_s_e", [self.sem_s_e[1]], out_f32=True)
+        low_o = self._gemm(emb[:, 2 * E:3 * E], "sem_o_e", [self.sem_o_e[1]], out_f32=True)
+        low_r = self._gemm(pf_reg, "sem_r", [self.sem_r[1]], out_f32=True)
+        sem = F.leaky_relu(low_s[X] + low_r[LCA] + low_o[Y], 0.1)
+        logit_sem = self._gemm(sem, "rel_sem", [self.relation_infer_sem[2]], out_f32=True)
+        part_s = self._gemm(det_s, "sem_s", [self.sem_s[0]], out_f32=True)
+        part_o = self._gemm(det_o, "sem_o", [self.sem_o[0]], out_f32=True)
+        logits = logit_spa + logit_sem + part_s[X] + part_o[Y]                   # :1066-1069
+        if cfg.USE_FREQ_BIAS:
+            lab = det_labels - 1
+            logits = logits + self.freq_bias.rel_index_with_labels(torch.stack((lab[X], lab[Y]), 1))  # :1064,:1075
+        prd = torch.sigmoid(logits) if cfg.MULTI_RELATION else F.softmax(logits, dim=1)   # :1083 / :1090
+
+        # ---- per-clip return dicts (:1162-1182)
+        outs = []
+        for b in range(B):
+            s, o = pairs[b][0], pairs[b][1]
+            rois_b = det_all[off[b]:off[b + 1]].copy()
+            rois_b[:, 0] = 0
+            sl = slice(int(poff[b]), int(poff[b + 1]))
+            ol = slice(int(off[b]), int(off[b + 1]))
+            d = dict(sbj_rois=rois_b[s], obj_rois=rois_b[o], det_rois=rois_b, sbj_inds=s, obj_inds=o,
+                     det_labels=det_labels[ol], det_scores=det_scores[ol],
+                     sbj_labels=det_labels[ol][up(s)], obj_labels=det_labels[ol][up(o)],
+                     sbj_scores=det_scores[ol][up(s)], obj_scores=det_scores[ol][up(o)],
+                     msp_det_scores=obj_score[ol], prd_scores=prd[sl], prd_ttl_scores=prd[sl])
+            if topk:
+                d.update(self.topk_triplets(d, topk, prd_k))
+            outs.append(d)
+        self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
+                           q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
+                           logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)
+        return outs
+
+    @staticmethod
+    def topk_triplets(d, topk, prd_k=1):
+        """Ranking core of lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 on device: top prd_k
+        predicates per pair, score = sbj*obj*prd, global top-k -> fixed-size triplet records."""
+        prd = d["prd_scores"]
+        sc, lab = torch.topk(prd, min(prd_k, prd.shape[1]), dim=1)
+        spo = (d["sbj_scores"] * d["obj_scores"])[:, None] * sc
+        k = min(topk, spo.numel())
+        top, idx = torch.topk(spo.reshape(-1), k)
+        pair = idx // sc.shape[1]
+        return dict(top_scores=top, top_pair=pair, top_prd=lab.reshape(-1)[idx],
+                    top_sbj=d["sbj_labels"][pair], top_obj=d["obj_labels"][pair])

@@ -114,53 +114,75 @@ def maxpool3d(x, ksize, stride, padding=(0, 0, 0)):
     return out
 
 
-def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False):
-    """C = alpha * A @ B^T (+bias)(+residual)(+ReLU).  A (M,K) or (b,M,K) bf16; B (N,K) or (b,N,K) bf16."""
-    A = _bf16(A, "A")
-    B = _bf16(B, "B")
-    batched = A.dim() == 3
-    if batched:
-        b, M, K = A.shape
-        if B.dim() == 3:
-            N = B.shape[1]
-            sB = N * K
-        else:
-            N = B.shape[0]
-            sB = 0
-        sA, sC = M * K, M * N
-        out_shape = (b, M, N)
-    else:
-        M, K = A.shape
-        N = B.shape[0]
-        b, sA, sB, sC = 1, 0, 0, 0
-        out_shape = (M, N)
+EPI_LEAKY = 8
+EPI_RES_POST = 16
+
+
+def _rows(t, name):
+    """(batch, rows, ld, batch_stride) of a 2-D/3-D bf16 operand whose last dim is contiguous."""
+    L.require_gpu(t)
+    if t.dtype != torch.bfloat16:
+        raise RuntimeError("%s must be bfloat16" % name)
+    if t.stride(-1) != 1:
+        raise RuntimeError("%s: last dimension must be contiguous" % name)
+    if t.dim() == 2:
+        return 1, t.shape[0], t.stride(0), 0
+    if t.dim() == 3:
+        return t.shape[0], t.shape[1], t.stride(1), t.stride(0)
+    raise RuntimeError("%s must be 2-D or 3-D" % name)
+
+
+def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False, leaky=False,
+            residual_post=False, out=None):
+    """C = alpha * A @ B^T (+bias)(+residual)(+ReLU | LeakyReLU(0.1))(+residual after the activation).
+    A (M,K) or (b,M,K); B (N,K) or (b,N,K); row-strided views are accepted (last dim contiguous).
+    `out` may be a row-strided view (e.g. a column slice of a wider zero-initialised buffer)."""
+    ba, M, lda, sA = _rows(A, "A")
+    bb, N, ldb, sB = _rows(B, "B")
+    K = A.shape[-1]
     if B.shape[-1] != K:
         raise RuntimeError("gemm_nt: K mismatch %s vs %s" % (tuple(A.shape), tuple(B.shape)))
-    out = torch.empty(out_shape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
-    epi = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    b = max(ba, bb)
+    if ba not in (1, b) or bb not in (1, b):
+        raise RuntimeError("gemm_nt: batch mismatch")
+    if A.dim() == 3 and ba == 1:
+        sA = 0
+    out_shape = (b, M, N) if (A.dim() == 3 or B.dim() == 3) else (M, N)
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    if out is None:
+        out = torch.empty(out_shape, dtype=odt, device=A.device)
+    else:
+        if tuple(out.shape) != out_shape or out.dtype != odt or out.stride(-1) != 1:
+            raise RuntimeError("gemm_nt: bad `out`")
+    ldc = out.stride(-2)
+    sC = out.stride(0) if out.dim() == 3 else 0
+    epi = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_LEAKY if leaky else 0)
     if residual is not None:
         residual = _bf16(residual, "residual")
-        if residual.shape != out.shape:
-            raise RuntimeError("gemm_nt: residual shape mismatch")
+        if tuple(residual.shape) != out_shape or not out.is_contiguous():
+            raise RuntimeError("gemm_nt: residual must match a contiguous output")
+        epi |= EPI_RES_POST if residual_post else EPI_RESIDUAL
     if bias is not None:
         bias = _f32(bias, "bias")
     with torch.cuda.device(A.device):
-        L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, K, K, N, b, sA, sB, sC, float(alpha),
+        L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
                                            L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.stream()),
                 "gemm_bf16_nt")
     return out
 
 
-def transpose(x):
-    """(b, R, C) bf16 -> (b, C, R) bf16 (or 2-D)."""
+def transpose(x, pad_to=1):
+    """(b, R, C) bf16 -> (b, C, Rp) bf16 with Rp = R rounded up to `pad_to` (zero filled); returns the
+    full padded tensor (2-D input -> 2-D output)."""
     x = _bf16(x, "x")
     two_d = x.dim() == 2
     if two_d:
         x = x.unsqueeze(0)
     b, R, C = x.shape
-    out = torch.empty((b, C, R), dtype=torch.bfloat16, device=x.device)
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    out = (torch.zeros if Rp != R else torch.empty)((b, C, Rp), dtype=torch.bfloat16, device=x.device)
     with torch.cuda.device(x.device):
-        L.check(L.lib().trace_transpose_bf16(L.ptr(x), b, R, C, L.ptr(out), L.stream()), "transpose")
+        L.check(L.lib().trace_transpose_bf16(L.ptr(x), b, R, C, L.ptr(out), Rp, C * Rp, L.stream()), "transpose")
     return out[0] if two_d else out
 
 
@@ -178,6 +200,23 @@ def roi_align_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
                                                       float(spatial_scale), pooled, pooled,
                                                       int(sampling_ratio), L.ptr(out), L.stream()),
                 "roi_align_nhwc")
+    return out
+
+
+def roi_align_avg_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
+    """ROIAlign + mean over the pooled bins: x (B,H,W,C) bf16, rois (K,5) f32 -> (K,C) bf16."""
+    x = _bf16(x, "x")
+    rois = _f32(rois, "rois")
+    B, H, W, C = x.shape
+    K = rois.shape[0]
+    out = torch.empty((K, C), dtype=torch.bfloat16, device=x.device)
+    if K == 0:
+        return out
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_roi_align_avg_nhwc_bf16(L.ptr(x), B, H, W, C, L.ptr(rois), K,
+                                                      float(spatial_scale), pooled, pooled,
+                                                      int(sampling_ratio), L.ptr(out), L.stream()),
+                "roi_align_avg_nhwc")
     return out
 
 

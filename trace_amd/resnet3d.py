@@ -1,0 +1,337 @@
+"""I3D ResNet-50 clip backbone on MI355X.
+
+Drop-in for lib/i3d/resnet3d.py `ResNet3d` (constructor :385-484, forward
+:785-802, Bottleneck3d :155-318) including the mmcv building blocks it imports
+(`ConvModule` = Conv3d + BN3d + ReLU, `NonLocal3d` dot-product / sub-sampled;
+call sites resnet3d.py:95,250,262,275,289,549,721).  Parameter names and shapes
+match the reference so its checkpoints load (`conv1.conv.weight`,
+`layer2.1.non_local_block.g.0.conv.weight`, ...).
+
+The forward pass does not run torch convolutions: activations are kept
+channels-last bf16 (N,T,H,W,C) and every Conv3d+BN(+residual)(+ReLU) is one
+implicit-GEMM launch of libtrace_amd.so with the eval-mode BatchNorm folded into
+the packed weights.  Inference only (the reference evaluates with
+`norm_eval`/`.eval()` BN statistics); training forward raises.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.modules.utils import _ntuple, _triple
+
+from . import ops
+
+
+class ConvModule(nn.Module):
+    """mmcv.cnn.ConvModule subset used by resnet3d.py: conv -> bn -> ReLU.
+    bias='auto' means "bias iff no norm" (mmcv semantics)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias='auto',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU')):
+        super().__init__()
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = nn.Conv3d(in_channels, out_channels, _triple(kernel_size), _triple(stride), _triple(padding),
+                              _triple(dilation), bias=bias)
+        if self.with_norm:
+            self.bn = nn.BatchNorm3d(out_channels)
+        self._packed = None
+
+    @property
+    def norm(self):
+        return self.bn if self.with_norm else None
+
+    def packed(self):
+        """(w (Cout, taps*Cin) bf16 with BN scale folded, bias (Cout) f32)."""
+        if self._packed is None:
+            w = self.conv.weight.detach().float()
+            cout = w.shape[0]
+            if self.with_norm:
+                scale = self.bn.weight.detach().float() / torch.sqrt(self.bn.running_var.float() + self.bn.eps)
+                shift = self.bn.bias.detach().float() - self.bn.running_mean.float() * scale
+            else:
+                scale = torch.ones(cout, device=w.device)
+                shift = torch.zeros(cout, device=w.device)
+            if self.conv.bias is not None:
+                shift = shift + self.conv.bias.detach().float() * scale
+            w = w * scale.view(-1, 1, 1, 1, 1)
+            wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous().to(torch.bfloat16)
+            self._packed = (wp, shift.contiguous())
+        return self._packed
+
+    def run(self, x, residual=None, relu=None):
+        """x channels-last bf16 (N,T,H,W,Cin) -> (N,To,Ho,Wo,Cout) bf16."""
+        w, b = self.packed()
+        c = self.conv
+        relu = self.with_activation if relu is None else relu
+        return ops.conv3d(x, w, b, c.kernel_size, c.stride, c.padding, c.dilation, residual=residual, relu=relu)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._packed = None
+        return super()._load_from_state_dict(*a, **k)
+
+
+class NonLocal3d(nn.Module):
+    """mmcv.cnn.NonLocal3d (mmcv 1.x `_NonLocalNd`), the configuration TRACE uses
+    (i3d_nl_dot_product_...py:15-19: sub_sample=True, use_scale=False,
+    mode='dot_product', BN on conv_out).  Source not vendored in the reference:
+    restated from mmcv's published behaviour (parity unpinned)."""
+
+    def __init__(self, in_channels, reduction=2, use_scale=True, conv_cfg=None, norm_cfg=None,
+                 mode='embedded_gaussian', sub_sample=False, **kwargs):
+        super().__init__()
+        if mode != 'dot_product':
+            raise NotImplementedError("only mode='dot_product' (TRACE's configuration) is built")
+        self.in_channels = in_channels
+        self.inter_channels = max(in_channels // reduction, 1)
+        self.use_scale = use_scale
+        self.sub_sample = sub_sample
+        c = self.inter_channels
+        g = ConvModule(in_channels, c, 1, act_cfg=None)
+        phi = ConvModule(in_channels, c, 1, act_cfg=None)
+        self.theta = ConvModule(in_channels, c, 1, act_cfg=None)
+        self.conv_out = ConvModule(c, in_channels, 1, norm_cfg=norm_cfg, act_cfg=None)
+        if sub_sample:
+            self.g = nn.Sequential(g, nn.MaxPool3d(kernel_size=(1, 2, 2)))
+            self.phi = nn.Sequential(phi, nn.MaxPool3d(kernel_size=(1, 2, 2)))
+        else:
+            self.g, self.phi = g, phi
+
+    def _conv(self, m):
+        return m[0] if isinstance(m, nn.Sequential) else m
+
+    def run(self, x):
+        N, T, H, W, C = x.shape
+        c = self.inter_channels
+        theta = self.theta.run(x)
+        phi = self._conv(self.phi).run(x)
+        g = self._conv(self.g).run(x)
+        if self.sub_sample:
+            phi = ops.maxpool3d(phi, (1, 2, 2), (1, 2, 2))
+            g = ops.maxpool3d(g, (1, 2, 2), (1, 2, 2))
+        nq = T * H * W
+        nkv = phi.shape[1] * phi.shape[2] * phi.shape[3]
+        # pairwise = theta^T phi / N_kv (dot_product: no softmax); y = pairwise g.  N_kv is padded
+        # to a multiple of 8 with zero columns (16-byte rows for the second product's operands).
+        nkp = (nkv + 7) // 8 * 8
+        pw_full = (torch.zeros if nkp != nkv else torch.empty)((N, nq, nkp), dtype=torch.bfloat16, device=x.device)
+        ops.gemm_nt(theta.view(N, nq, c), phi.view(N, nkv, c), alpha=1.0 / nkv, out=pw_full[:, :, :nkv])
+        y = ops.gemm_nt(pw_full, ops.transpose(g.view(N, nkv, c), pad_to=8))
+        return self.conv_out.run(y.view(N, T, H, W, c), residual=x, relu=False)  # x + conv_out(y)
+
+
+class Bottleneck3d(nn.Module):
+    """resnet3d.py:155-318."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, spatial_stride=1, temporal_stride=1, dilation=1, downsample=None,
+                 style='pytorch', inflate=True, inflate_style='3x1x1', non_local=False, non_local_cfg=dict(),
+                 conv_cfg=dict(type='Conv3d'), norm_cfg=dict(type='BN3d'), act_cfg=dict(type='ReLU'),
+                 with_cp=False, **kwargs):
+        super().__init__()
+        assert style in ['pytorch', 'caffe']
+        assert inflate_style in ['3x1x1', '3x3x3']
+        if style == 'pytorch':
+            c1s, c2s, c1t, c2t = 1, spatial_stride, 1, temporal_stride
+        else:
+            c1s, c2s, c1t, c2t = spatial_stride, 1, temporal_stride, 1
+        if inflate:
+            if inflate_style == '3x1x1':
+                k1, p1, k2, p2 = (3, 1, 1), (1, 0, 0), (1, 3, 3), (0, dilation, dilation)
+            else:
+                k1, p1, k2, p2 = (1, 1, 1), (0, 0, 0), (3, 3, 3), (1, dilation, dilation)
+        else:
+            k1, p1, k2, p2 = (1, 1, 1), (0, 0, 0), (1, 3, 3), (0, dilation, dilation)
+        self.conv1 = ConvModule(inplanes, planes, k1, stride=(c1t, c1s, c1s), padding=p1, bias=False,
+                                norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.conv2 = ConvModule(planes, planes, k2, stride=(c2t, c2s, c2s), padding=p2, dilation=(1, dilation, dilation),
+                                bias=False, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.conv3 = ConvModule(planes, planes * self.expansion, 1, bias=False, norm_cfg=norm_cfg, act_cfg=None)
+        self.downsample = downsample
+        self.non_local = non_local
+        if non_local:
+            self.non_local_block = NonLocal3d(planes * self.expansion, **non_local_cfg)
+
+    def run(self, x):
+        identity = x if self.downsample is None else self.downsample.run(x)
+        out = self.conv2.run(self.conv1.run(x))
+        out = self.conv3.run(out, residual=identity, relu=True)  # resnet3d.py:306,313
+        if self.non_local:
+            out = self.non_local_block.run(out)
+        return out
+
+
+class ResNet3d(nn.Module):
+    """resnet3d.py:321-811 (Bottleneck depths)."""
+    arch_settings = {50: (Bottleneck3d, (3, 4, 6, 3)), 101: (Bottleneck3d, (3, 4, 23, 3)),
+                     152: (Bottleneck3d, (3, 8, 36, 3))}
+
+    def __init__(self, depth, pretrained=None, pretrained2d=True, in_channels=3, num_stages=4, base_channels=64,
+                 spatial_strides=(1, 2, 2, 2), temporal_strides=(1, 1, 1, 1), dilations=(1, 1, 1, 1),
+                 conv1_kernel=(5, 7, 7), conv1_stride_t=2, pool1_stride_t=2, with_pool2=True, style='pytorch',
+                 frozen_stages=-1, inflate=(1, 1, 1, 1), inflate_style='3x1x1', conv_cfg=dict(type='Conv3d'),
+                 norm_cfg=dict(type='BN3d', requires_grad=True), act_cfg=dict(type='ReLU', inplace=True),
+                 norm_eval=True, with_cp=False, non_local=(0, 0, 0, 0), non_local_cfg=dict(),
+                 zero_init_residual=True, type=None, **kwargs):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError('invalid depth %s for resnet' % depth)
+        self.depth = depth
+        self.pretrained = pretrained
+        self.in_channels = in_channels
+        self.base_channels = base_channels
+        self.num_stages = num_stages
+        assert 1 <= num_stages <= 4
+        assert len(spatial_strides) == len(temporal_strides) == len(dilations)
+        self.conv1_kernel = _triple(conv1_kernel)
+        self.conv1_stride_t = conv1_stride_t
+        self.pool1_stride_t = pool1_stride_t
+        self.with_pool2 = with_pool2
+        self.frozen_stages = frozen_stages
+        self.norm_eval = norm_eval
+        self.block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks
+        stage_inflations = _ntuple(num_stages)(inflate)
+        non_local_stages = _ntuple(num_stages)(non_local)
+        self.inplanes = base_channels
+
+        self.conv1 = ConvModule(in_channels, base_channels, self.conv1_kernel, stride=(conv1_stride_t, 2, 2),
+                                padding=tuple((k - 1) // 2 for k in self.conv1_kernel), bias=False,
+                                norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.maxpool = nn.MaxPool3d(kernel_size=(1, 3, 3), stride=(pool1_stride_t, 2, 2), padding=(0, 1, 1))
+        self.pool2 = nn.MaxPool3d(kernel_size=(2, 1, 1), stride=(2, 1, 1))
+
+        self.res_layers = []
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = base_channels * 2 ** i
+            layer = self.make_res_layer(self.block, self.inplanes, planes, num_blocks,
+                                        spatial_stride=spatial_strides[i], temporal_stride=temporal_strides[i],
+                                        dilation=dilations[i], style=style, norm_cfg=norm_cfg, act_cfg=act_cfg,
+                                        non_local=non_local_stages[i], non_local_cfg=non_local_cfg,
+                                        inflate=stage_inflations[i], inflate_style=inflate_style)
+            self.inplanes = planes * self.block.expansion
+            name = 'layer%d' % (i + 1)
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+        self.feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks[:num_stages]) - 1)
+        self.final_feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks) - 1)
+        self._stem_packed = None
+
+    @staticmethod
+    def make_res_layer(block, inplanes, planes, blocks, spatial_stride=1, temporal_stride=1, dilation=1,
+                       style='pytorch', inflate=1, inflate_style='3x1x1', non_local=0, non_local_cfg=dict(),
+                       norm_cfg=None, act_cfg=None, **kwargs):
+        inflate = inflate if not isinstance(inflate, int) else (inflate,) * blocks
+        non_local = non_local if not isinstance(non_local, int) else (non_local,) * blocks
+        assert len(inflate) == blocks and len(non_local) == blocks
+        downsample = None
+        if spatial_stride != 1 or inplanes != planes * block.expansion:
+            downsample = ConvModule(inplanes, planes * block.expansion, 1,
+                                    stride=(temporal_stride, spatial_stride, spatial_stride), bias=False,
+                                    norm_cfg=norm_cfg, act_cfg=None)
+        layers = [block(inplanes, planes, spatial_stride=spatial_stride, temporal_stride=temporal_stride,
+                        dilation=dilation, downsample=downsample, style=style, inflate=(inflate[0] == 1),
+                        inflate_style=inflate_style, non_local=(non_local[0] == 1), non_local_cfg=non_local_cfg,
+                        norm_cfg=norm_cfg, act_cfg=act_cfg)]
+        inplanes = planes * block.expansion
+        for i in range(1, blocks):
+            layers.append(block(inplanes, planes, spatial_stride=1, temporal_stride=1, dilation=dilation, style=style,
+                                inflate=(inflate[i] == 1), inflate_style=inflate_style, non_local=(non_local[i] == 1),
+                                non_local_cfg=non_local_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg))
+        return nn.Sequential(*layers)
+
+    # -- stem ---------------------------------------------------------------
+    CP = 4  # clip channels padded 3 -> 4 (8-byte pixels)
+
+    def _stem_weights(self):
+        if self._stem_packed is None:
+            kt, kh, kw = self.conv1_kernel
+            kwp = (kw + 1) // 2 * 2  # even number of pixels: kwp*CP % 8 == 0
+            w, b = self.conv1.conv.weight.detach().float(), None
+            bn = self.conv1.bn
+            scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+            b = bn.bias.detach().float() - bn.running_mean.float() * scale
+            w = w * scale.view(-1, 1, 1, 1, 1)
+            wp = torch.zeros((w.shape[0], kt, kh, kwp, self.CP), device=w.device)
+            wp[:, :, :, :kw, :w.shape[1]] = w.permute(0, 2, 3, 4, 1)
+            self._stem_packed = (wp.reshape(w.shape[0], -1).to(torch.bfloat16).contiguous(), b.contiguous(), kwp)
+        return self._stem_packed
+
+    def _run_stem(self, x, in_ntchw):
+        """conv1 + BN + ReLU + maxpool (resnet3d.py:795-796).  The pool's kernel_t is 1 with
+        stride_t 2, so only every second conv1 frame is ever read: the stem runs with temporal
+        stride conv1_stride_t*pool1_stride_t and the pool with temporal stride 1."""
+        if in_ntchw:
+            N, T, C, H, W = x.shape
+        else:
+            N, C, T, H, W = x.shape
+        if C > self.CP:
+            raise RuntimeError("stem expects <= %d input channels" % self.CP)
+        kt, kh, kw = self.conv1_kernel
+        w, b, kwp = self._stem_weights()
+        pt, ph, pw = (kt - 1) // 2, (kh - 1) // 2, (kw - 1) // 2
+        T1 = (T + 2 * pt - kt) // self.conv1_stride_t + 1
+        To = (T1 - 1) // self.pool1_stride_t + 1
+        Ho = (H + 2 * ph - kh) // 2 + 1
+        Wo = (W + 2 * pw - kw) // 2 + 1
+        need_w = (Wo - 1) * 2 + kwp  # padded width the contiguous runs must fit in
+        pw1 = max(need_w - (W + pw), pw)
+        if (W + pw + pw1) % 2:
+            pw1 += 1
+        xp = ops.clip_to_ndhwc(x, in_ntchw, self.CP, (pt, pt, ph, ph, pw, pw1))
+        y = ops.conv3d_stem(xp, w, b, kt, kh, kwp, (self.conv1_stride_t * self.pool1_stride_t, 2, 2), (To, Ho, Wo))
+        return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+
+    def forward_ndhwc(self, x, in_ntchw=False):
+        """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw) -> channels-last bf16 (N,T',H',W',feat_dim)."""
+        if self.training:
+            raise NotImplementedError("trace_amd.ResNet3d implements the inference path; call .eval()")
+        with torch.no_grad():
+            x = self._run_stem(x, in_ntchw)
+            for i, name in enumerate(self.res_layers[:self.num_stages]):
+                for blk in getattr(self, name):
+                    x = blk.run(x)
+                if i == 0 and self.with_pool2:
+                    x = ops.maxpool3d(x, (2, 1, 1), (2, 1, 1))
+        return x
+
+    def forward(self, x):
+        """Reference signature (resnet3d.py:785-802): (N,C,T,H,W) f32 -> (N,feat_dim,T',H',W') f32."""
+        y = self.forward_ndhwc(x)
+        return y.permute(0, 4, 1, 2, 3).float()
+
+    def _apply(self, fn, *a, **k):
+        self._stem_packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._stem_packed = None
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        """resnet3d.py:804-811 (returns None like the reference)."""
+        super().train(mode)
+        if self.frozen_stages >= 0:
+            self.conv1.eval()
+        for i in range(1, self.frozen_stages + 1):
+            getattr(self, 'layer%d' % i).eval()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    m.eval()
+
+
+def i3d_dc5_config():
+    """Backbone kwargs TRACE builds (i3d_nl_dot_product_...py:4-20 with the I3D_DC5 overrides of
+    lib/modeling_rel/model_builder_rel.py:166-183)."""
+    return dict(depth=50, pretrained=None, pretrained2d=True, num_stages=4, conv_cfg=dict(type='Conv3d'),
+                norm_eval=False, frozen_stages=0,
+                inflate=((1, 1, 1), (1, 0, 1, 0), (1, 0, 1, 0, 1, 0), (0, 1, 0)),
+                non_local=((0, 0, 0), (0, 1, 0, 1), (0, 1, 0, 1, 0, 1), (0, 0, 0)),
+                non_local_cfg=dict(sub_sample=True, use_scale=False, norm_cfg=dict(type='BN3d', requires_grad=True),
+                                   mode='dot_product'),
+                zero_init_residual=False, dilations=(1, 1, 1, 2), spatial_strides=(1, 2, 2, 1))
