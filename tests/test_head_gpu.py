@@ -1,0 +1,92 @@
+"""Relation head (ROIAlign -> heads -> temporal attention -> box tree / tree-GRU -> pair attention ->
+scoring): HIP path on B clips vs the fp32 oracle run clip by clip on the SAME temporal maps.
+Tolerances (north_star): features rtol 2e-2 of the feature scale (bf16 vs fp32); relation
+triplets: top-100 >= 99 % identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rel(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return float((got - ref).norm() / (ref.norm() + 1e-12)), float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from trace_amd.model_builder_rel import Generalized_RCNN
+    from trace_amd.synthetic import make_inputs, randomize_model
+    from oracle.i3d_ref import calibrate_bn
+    torch.manual_seed(1)
+    m = Generalized_RCNN()
+    randomize_model(m, 1)
+    calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
+    m.Prd_RCNN.load_state_dict(calibrate_bn(m.Prd_RCNN.state_dict(), calib))
+    m.eval()
+    return m
+
+
+def test_state_dict_names(setup):
+    sd = setup.state_dict()
+    for k in ("Box_Head.fc1.weight", "S_Head.fc2.bias", "O_Head.fc1.weight", "Box_Outs.cls_score.weight",
+              "cem_Box_Outs.cls_score.bias", "Prd_RCNN.layer3.1.non_local_block.theta.conv.weight",
+              "cluster_tree3d.fc_r.0.weight", "cluster_tree3d.r2c.1.weight", "cluster_tree3d.FFN.1.bias",
+              "cluster_tree3d.tree_message_passing_list.3.Urd.0.bias", "cluster_tree3d.temporal_obj_fc.fc2.weight",
+              "cluster_tree3d.temporal_r_feat_val.1.weight", "cluster_tree3d.temporal_obj_atten_q_s.0.weight",
+              "embed_obj_det.weight", "after_obj_det_embed.1.weight", "restore_obj_feat.1.bias",
+              "spatio_atten_s.1.weight", "spatio_atten_map.weight", "atten_q_map.bias", "spatio_inferA.0.weight",
+              "spatio_infer_fc.0.weight", "sem_s.0.weight", "sem_s_e.1.weight", "sem_r.1.weight",
+              "relation_infer_sem.2.weight", "relation_infer_spa.2.bias", "freq_bias.rel_baseline.weight"):
+        assert k in sd, k
+    assert "cem_Box_Outs.bbox_pred.weight" not in sd            # model_builder_rel.py:420
+    assert sd["Box_Head.fc1.weight"].shape == (1024, 100352)
+    assert sd["spatio_infer_fc.0.weight"].shape == (256, 12544)
+    assert sd["freq_bias.rel_baseline.weight"].shape == (35 * 35, 132)
+
+
+@pytest.mark.parametrize("B,T,n", [(2, 8, 10), (1, 17, 6)])
+def test_head_matches_oracle(setup, B, T, n):
+    from oracle.head_ref import head_forward
+    from trace_amd.synthetic import make_inputs
+    m = setup
+    frames, blob, feat, rois = make_inputs(B, T, n, 224, seed=3 + B)
+    if B == 2:
+        rois[1] = rois[1][:7]          # ragged: clips with different object counts
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    m.to(DEV)
+    outs = m(frames.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2)
+    dbg = m._debug
+    tm = dbg["tmaps"].float().permute(0, 1, 4, 2, 3).cpu()          # (B,T',C,h,w): the HIP path's I3D output
+    off = 0
+    poff = 0
+    for b in range(B):
+        nb = rois[b].shape[0]
+        ref = head_forward(sd, blob[b:b + 1], feat[b:b + 1], tm[b], rois[b])
+        o = outs[b]
+        P = len(ref["sbj_inds"])
+        assert np.array_equal(o["sbj_inds"], ref["sbj_inds"]) and np.array_equal(o["obj_inds"], ref["obj_inds"])
+        assert np.array_equal(o["det_labels"].cpu().numpy().astype(np.int32), ref["det_labels"])
+        for name, got, want in (
+                ("det_feat", dbg["det_feat"][off:off + nb], ref["det_feat"]),
+                ("obj_agg", dbg["obj_agg"][off:off + nb], ref["obj_agg"]),
+                ("obj_feature", dbg["obj_feature"][off:off + nb], ref["obj_feature"]),
+                ("q_s", dbg["q_s"][off:off + nb], ref["q_s"]),
+                ("s_map", dbg["s_map"][poff:poff + P].view(P, 49, 256).permute(0, 2, 1).reshape(P, 256, 7, 7), ref["s_map"]),
+                ("v_map", dbg["v_map"][poff:poff + P].view(P, 49, 256).permute(0, 2, 1).reshape(P, 256, 7, 7), ref["v_p"]),
+                ("logits", dbg["logits"][poff:poff + P], ref["logits"]),
+                ("obj_score", o["msp_det_scores"], ref["obj_scores"])):
+            l2, mx = rel(got, want)
+            assert l2 < 2e-2, (b, name, l2, mx)
+        np.testing.assert_allclose(o["prd_scores"].cpu().numpy(), ref["prd_scores"].numpy(), atol=2e-2)
+        # top-100 triplets (task_evaluation_vg_and_vrd.py:207-228): >= 99 % identical
+        from oracle.np_oracle import topk_triplets
+        rs = ref["det_scores"]
+        sc, pair, prd = topk_triplets(ref["prd_scores"].numpy(), rs[ref["sbj_inds"]], rs[ref["obj_inds"]], 2, 100)
+        want = set(zip(pair.tolist(), prd.tolist()))
+        got = set(zip(o["top_pair"].cpu().tolist(), o["top_prd"].cpu().tolist()))
+        assert len(want & got) >= 0.99 * len(want), (b, len(want & got), len(want))
+        off += nb
+        poff += P

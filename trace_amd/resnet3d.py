@@ -118,8 +118,12 @@ class NonLocal3d(nn.Module):
         # pairwise = theta^T phi / N_kv (dot_product: no softmax); y = pairwise g.  N_kv is padded
         # to a multiple of 8 with zero columns (16-byte rows for the second product's operands).
         nkp = (nkv + 7) // 8 * 8
-        pw_full = (torch.zeros if nkp != nkv else torch.empty)((N, nq, nkp), dtype=torch.bfloat16, device=x.device)
-        ops.gemm_nt(theta.view(N, nq, c), phi.view(N, nkv, c), alpha=1.0 / nkv, out=pw_full[:, :, :nkv])
+        phi = phi.view(N, nkv, c)
+        if nkp != nkv:  # odd map sizes only: zero key rows give zero pairwise columns
+            phi_p = torch.zeros((N, nkp, c), dtype=torch.bfloat16, device=x.device)
+            phi_p[:, :nkv] = phi
+            phi = phi_p
+        pw_full = ops.gemm_nt(theta.view(N, nq, c), phi, alpha=1.0 / nkv)
         y = ops.gemm_nt(pw_full, ops.transpose(g.view(N, nkv, c), pad_to=8))
         return self.conv_out.run(y.view(N, T, H, W, c), residual=x, relu=False)  # x + conv_out(y)
 
