@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of TRACE's per-clip relation hot path (I3D-R50 backbone ->
+ROIAlign -> context aggregation + relation scoring) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of synthetic clips per GPU: the workload
+BASELINE.json's metric is quoted on (configs[1]: VidVRD res101xi3d50 setting, 32-frame 224^2 clips,
+batch 8 per GPU, 20 objects / 380 pairs per clip, bf16).  Clips shard across ranks with no data-path
+collective (weak scaling); the per-video top-100 triplet records are all-gathered (RCCL) once after
+the timed region, as the sweep does.  Inputs are resident in HBM before timing.
+
+Prints ONE JSON line (rank 0) with the driver contract fields plus
+  roofline     - dominant kernel (bf16 MFMA implicit-GEMM family): algorithmic FLOPs / launch time,
+                 measured with events on the launch stream inside the timed steps
+  cpu_baseline - the CPU oracle (a port of the reference path) timed on the host cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK = 2.5e15  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+I3D_GFLOP_PER_CLIP = 108.1  # reference algorithm @ 32 x 224^2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--objects", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trace", action="store_true", help="skip per-launch events (roofline leg)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
+    """CPU oracle ("port" of the reference path: oracle/i3d_ref.py + oracle/head_ref.py, fp32) on a
+    bounded sample of the same workload: whole clips, one at a time as the reference does."""
+    from oracle.i3d_ref import i3d_forward
+    from oracle.head_ref import head_forward
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    cores = torch.get_num_threads()
+    i3d_sd = {k[len("Prd_RCNN."):]: v for k, v in model_sd.items() if k.startswith("Prd_RCNN.")}
+    done, t0 = 0, time.time()
+    with torch.no_grad():
+        while done < frames.shape[0] and (done == 0 or time.time() - t0 < budget_s):
+            b = done
+            tm = i3d_forward(i3d_sd, frames[b:b + 1].permute(0, 2, 1, 3, 4).contiguous())   # (1,C,T',h,w)
+            head_forward(model_sd, blob[b:b + 1], feat[b:b + 1], tm[0].permute(1, 0, 2, 3).contiguous(), rois[b])
+            done += 1
+    dt = time.time() - t0
+    return dict(value=done / dt, unit="clips/sec", cores=cores, kind="port",
+                sample="%d clip(s) of the bench workload (%df 224^2, %d objects), fp32, one clip per call"
+                       % (done, frames.shape[1], rois[0].shape[0]))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist = dist_mod
+
+    from trace_amd import ops
+    from trace_amd.model_builder_rel import Generalized_RCNN
+    from trace_amd.synthetic import make_inputs, randomize_model
+    from trace_amd.dist import gather_triplets
+
+    torch.manual_seed(1)
+    model = Generalized_RCNN()
+    randomize_model(model, 1)
+    model.eval()
+    sd_cpu = None
+    model.to(dev)
+    calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
+    model.Prd_RCNN.calibrate_bn(calib.to(dev))       # setup only: sane activations for random weights
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd_cpu = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+
+    B, T, n = args.batch, args.frames, args.objects
+    frames_c, blob_c, feat_c, rois = make_inputs(B, T, n, 224, seed=1 + rank)
+    frames = frames_c.to(dev)
+    blob = blob_c.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)    # Conv_Body output, channels-last
+    feat = feat_c.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)    # Prd_RCNN2D output
+
+    def step():
+        return model(frames, blob, feat, rois, topk=100, prd_k=1)
+
+    for _ in range(args.warmup):
+        outs = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    trace = None if args.no_trace else []
+    ops.IGEMM_TRACE = trace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ops.IGEMM_TRACE = None
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the sweep's single exchange step: all-gather the fixed-size top-100 records of every clip
+    rec = gather_triplets(outs, 100, clip_offset=rank * B)
+    assert rec.shape[0] == world * B
+
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+    value = world * B * args.steps / dt
+    roof = None
+    if trace:
+        ms = [s.elapsed_time(e) for s, e, _ in trace]
+        fl = [f for _, _, f in trace]
+        avg_ms = sum(ms) / len(ms)
+        achieved = (sum(fl) / len(fl)) / (avg_ms * 1e-3)      # avg algorithmic FLOPs per launch / avg launch duration
+        roof = dict(bound="mfma", achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
+                    frac=achieved / MFMA_BF16_PEAK, traffic=None, kernel="trace::igemm_bf16_kernel<*>",
+                    launches_per_step=len(trace) // args.steps, avg_launch_us=avg_ms * 1e3,
+                    gflop_per_step=sum(fl) / args.steps / 1e9)
+    cpu = None
+    if sd_cpu is not None:
+        cpu = cpu_baseline(sd_cpu, frames_c, blob_c, feat_c, rois)
+    out = {
+        "metric": "clips/sec (32f 224^2, I3D-R50 + TRACE head)",
+        "value": value, "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "VidVRD res101xi3d50 setting (configs[1]): %d-frame 224^2 clips, batch %d per GPU, "
+                               "%d objects (%d pairs) per clip, I3D-R50-DC5 + ROIAlign + TRACE relation head; "
+                               "2-D conv-body outputs synthetic" % (T, B, n, n * (n - 1)),
+                   "clips_per_gpu": B, "frames": T, "objects": n, "parallelism": "clip-sharded x%d" % world},
+        "roofline": roof, "cpu_baseline": cpu,
+        "i3d_algorithmic_tflops": value * I3D_GFLOP_PER_CLIP / 1e3,
+    }
+    print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

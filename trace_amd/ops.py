@@ -13,6 +13,28 @@ EPI_RELU = 1
 EPI_RESIDUAL = 2
 EPI_OUT_F32 = 4
 
+# When set to a list, every igemm launch (conv3d / conv3d_stem / gemm_nt) is bracketed by a pair of
+# events on the launch stream and (start, end, algorithmic_flops) is appended: bench.py's roofline leg.
+IGEMM_TRACE = None
+
+
+class _span:
+    def __init__(self, flops):
+        self.flops = flops
+
+    def __enter__(self):
+        if IGEMM_TRACE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if IGEMM_TRACE is not None:
+            self.e.record()
+            IGEMM_TRACE.append((self.s, self.e, self.flops))
+        return False
+
 TREE_MAX_LEVELS = 12
 
 
@@ -74,7 +96,7 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
             raise RuntimeError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(out.shape)))
     if bias is not None:
         bias = _f32(bias, "bias")
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _span(2.0 * out.numel() * kt * kh * kw * Cin):
         L.check(L.lib().trace_conv3d_igemm_bf16(
             L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
             stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
@@ -82,8 +104,9 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
     return out
 
 
-def conv3d_stem(xp, w, bias, kt, kh, kwp, stride, out_thw, relu=True):
-    """Stem conv on the halo-padded clip xp (N,Tp,Hp,Wp,Cp) bf16; w (Cout, kt*kh*kwp*Cp)."""
+def conv3d_stem(xp, w, bias, kt, kh, kwp, stride, out_thw, relu=True, alg_k=None):
+    """Stem conv on the halo-padded clip xp (N,Tp,Hp,Wp,Cp) bf16; w (Cout, kt*kh*kwp*Cp).
+    alg_k = true (unpadded) reduction length kt*kh*kw*Cin, for FLOP accounting."""
     xp = _bf16(xp, "xp")
     w = _bf16(w, "w")
     N, Tp, Hp, Wp, Cp = xp.shape
@@ -92,7 +115,7 @@ def conv3d_stem(xp, w, bias, kt, kh, kwp, stride, out_thw, relu=True):
     out = torch.empty((N, To, Ho, Wo, Cout), dtype=torch.bfloat16, device=xp.device)
     if bias is not None:
         bias = _f32(bias, "bias")
-    with torch.cuda.device(xp.device):
+    with torch.cuda.device(xp.device), _span(2.0 * out.numel() * (alg_k or kt * kh * kwp * Cp)):
         L.check(L.lib().trace_conv3d_stem_bf16(L.ptr(xp), N, Tp, Hp, Wp, Cp, L.ptr(w), L.ptr(bias), Cout,
                                                kt, kh, kwp, stride[0], stride[1], stride[2], To, Ho, Wo,
                                                EPI_RELU if relu else 0, L.ptr(out), L.stream()),
@@ -164,7 +187,7 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
         epi |= EPI_RES_POST if residual_post else EPI_RESIDUAL
     if bias is not None:
         bias = _f32(bias, "bias")
-    with torch.cuda.device(A.device):
+    with torch.cuda.device(A.device), _span(2.0 * b * M * N * K):
         L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
                                            L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.stream()),
                 "gemm_bf16_nt")

@@ -59,6 +59,14 @@ class ConvModule(nn.Module):
             self._packed = (wp, shift.contiguous())
         return self._packed
 
+    def forward(self, x):
+        """Plain torch path (NCTHW f32, autograd-capable): used for training-side work and for
+        calibrating synthetic BN statistics; the inference hot path is `run`."""
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        return torch.relu(x) if self.with_activation else x
+
     def run(self, x, residual=None, relu=None):
         """x channels-last bf16 (N,T,H,W,Cin) -> (N,To,Ho,Wo,Cout) bf16."""
         w, b = self.packed()
@@ -103,6 +111,17 @@ class NonLocal3d(nn.Module):
 
     def _conv(self, m):
         return m[0] if isinstance(m, nn.Sequential) else m
+
+    def forward(self, x):
+        n = x.size(0)
+        c = self.inter_channels
+        g_x = self.g(x).view(n, c, -1).permute(0, 2, 1)
+        theta_x = self.theta(x).view(n, c, -1).permute(0, 2, 1)
+        phi_x = self.phi(x).view(n, c, -1)
+        pw = torch.matmul(theta_x, phi_x)
+        pw = pw / pw.shape[-1]
+        y = torch.matmul(pw, g_x).permute(0, 2, 1).contiguous().reshape(n, c, *x.size()[2:])
+        return x + self.conv_out(y)
 
     def run(self, x):
         N, T, H, W, C = x.shape
@@ -159,6 +178,11 @@ class Bottleneck3d(nn.Module):
         self.non_local = non_local
         if non_local:
             self.non_local_block = NonLocal3d(planes * self.expansion, **non_local_cfg)
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = torch.relu(self.conv3(self.conv2(self.conv1(x))) + identity)
+        return self.non_local_block(out) if self.non_local else out
 
     def run(self, x):
         identity = x if self.downsample is None else self.downsample.run(x)
@@ -287,7 +311,8 @@ class ResNet3d(nn.Module):
         if (W + pw + pw1) % 2:
             pw1 += 1
         xp = ops.clip_to_ndhwc(x, in_ntchw, self.CP, (pt, pt, ph, ph, pw, pw1))
-        y = ops.conv3d_stem(xp, w, b, kt, kh, kwp, (self.conv1_stride_t * self.pool1_stride_t, 2, 2), (To, Ho, Wo))
+        y = ops.conv3d_stem(xp, w, b, kt, kh, kwp, (self.conv1_stride_t * self.pool1_stride_t, 2, 2), (To, Ho, Wo),
+                            alg_k=kt * kh * kw * C)
         return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
     def forward_ndhwc(self, x, in_ntchw=False):
@@ -307,6 +332,36 @@ class ResNet3d(nn.Module):
         """Reference signature (resnet3d.py:785-802): (N,C,T,H,W) f32 -> (N,feat_dim,T',H',W') f32."""
         y = self.forward_ndhwc(x)
         return y.permute(0, 4, 1, 2, 3).float()
+
+    def forward_torch(self, x):
+        """The same network through torch's own Conv3d/BatchNorm3d modules (autograd-capable).  Not the
+        inference path: used to calibrate synthetic BN statistics and kept for the training row."""
+        x = self.maxpool(self.conv1(x))
+        for i, name in enumerate(self.res_layers[:self.num_stages]):
+            x = getattr(self, name)(x)
+            if i == 0 and self.with_pool2:
+                x = self.pool2(x)
+        return x
+
+    def calibrate_bn(self, clip):
+        """Synthetic-weight helper: set every BatchNorm's running statistics to the batch statistics of
+        `clip` (N,C,T,H,W) so that random weights give O(1) activations like a trained checkpoint."""
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm3d)]
+        saved = [(m.momentum, m.training) for m in bns]
+        for m in bns:
+            m.reset_running_stats()
+            m.momentum = None
+            m.train(True)
+        with torch.no_grad():
+            self.forward_torch(clip)
+        for m, (mom, tr) in zip(bns, saved):
+            m.momentum = mom
+            m.train(tr)
+            m.running_var.clamp_(min=0.1 * float(m.running_var.mean()) + 1e-6)
+        for m in self.modules():
+            if isinstance(m, ConvModule):
+                m._packed = None
+        self._stem_packed = None
 
     def _apply(self, fn, *a, **k):
         self._stem_packed = None
