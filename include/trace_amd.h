@@ -158,13 +158,17 @@ int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
  *   in   (N,Ti,Hi,Wi,Cin)  bf16 channels-last, Cin % 8 == 0
  *   w    (Cout, kt*kh*kw*Cin) bf16, tap-major / channel-minor, BN scale folded
  *   bias (Cout) f32 (BN shift, or conv bias)
- *   out  (N,To,Ho,Wo,Cout) bf16 (or f32 with TRACE_EPI_OUT_F32), Cout % 8 == 0 */
+ *   out  (N,To,Ho,Wo,Cout) bf16 (or f32 with TRACE_EPI_OUT_F32), Cout % 8 == 0
+ *   workspace: optional caller-owned device scratch (16-byte aligned; NULL = none).  When the
+ *   tile grid cannot fill the chip and K is deep, K is split over workgroups that write f32
+ *   partial slabs there and a second launch reduces them in slice order (deterministic). */
 int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi, int Wi,
                             int Cin, const uint16_t* w, const float* bias,
                             int Cout, int kt, int kh, int kw, int st, int sh,
                             int sw, int pt, int ph, int pw, int dt, int dh,
                             int dw, const uint16_t* residual, int epilogue,
-                            void* out, trace_stream_t stream);
+                            void* out, void* workspace, size_t workspace_bytes,
+                            trace_stream_t stream);
 
 /* The I3D stem (resnet3d.py:721-730: Conv3d 3->64, k(5,7,7), s(2,2,2)) on the
  * halo-padded channels-last clip written by trace_clip_to_ndhwc_bf16: Cin=3 is
@@ -197,6 +201,7 @@ int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
                        long long strideA, long long strideB, long long strideC,
                        float alpha, const float* bias,
                        const uint16_t* residual, int epilogue, void* C,
+                       void* workspace, size_t workspace_bytes,
                        trace_stream_t stream);
 
 /* bf16 (rows, cols) -> bf16 (cols, rows) per batch, output row stride ld_out

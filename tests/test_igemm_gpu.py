@@ -80,7 +80,8 @@ def test_conv3d_stem_matches_strided_conv():
         _close(got, ref[:, :, ::(st // 2)])
 
 
-@pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024),
+                                   (96, 384, 16384), (20, 64, 4096)])  # last two: split-K path
 def test_gemm_nt(shape):
     from trace_amd import ops
     M, N, K = shape
@@ -105,6 +106,8 @@ def test_gemm_nt_batched_and_transpose():
     _close(out.cpu(), ref)
     t = ops.transpose(B.to(DEV))
     assert torch.equal(t.cpu(), B.transpose(1, 2).contiguous())
+    tp = ops.transpose(B.to(DEV), pad_to=8)                       # zero-padded rows (52 -> 56)
+    assert tp.shape == (3, 64, 56) and torch.equal(tp[:, :, :52].cpu(), B.transpose(1, 2)) and float(tp[:, :, 52:].abs().max()) == 0
 
 
 def test_maxpool3d():

@@ -221,15 +221,26 @@ struct TreeParams {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// dot of column j of a transposed (n_in, Hd) matrix with a strided vector
+// dot of column j of a transposed (n_in, Hd) matrix (LDS or global) with a contiguous vector;
+// n_in % 4 == 0 (checked by the host wrapper): 16-byte broadcast loads of v, 4 partial sums.
 __device__ __forceinline__ float dot_col(const float* __restrict__ Wt, int Hd, int j,
                                          const float* __restrict__ v, int n_in) {
-  float s = 0.f;
-  for (int i = 0; i < n_in; ++i) s += Wt[(long long)i * Hd + j] * v[i];
-  return s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int i = 0; i < n_in; i += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(v + i);
+    s0 += Wt[(i + 0) * Hd + j] * x.x;
+    s1 += Wt[(i + 1) * Hd + j] * x.y;
+    s2 += Wt[(i + 2) * Hd + j] * x.z;
+    s3 += Wt[(i + 3) * Hd + j] * x.w;
+  }
+  return (s0 + s1) + (s2 + s3);
 }
 
+// LDS = true: the six weight matrices of the current direction are staged in LDS (lane j reads
+// consecutive banks, the vector element is a broadcast); false: read through L1/L2 (large Hd).
+template <bool LDS>
 __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int t = blockIdx.x, g = blockIdx.y;
   const TreeW& w = p.w[g];
   const int F = p.F, Hd = p.Hd;
@@ -241,14 +252,36 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
   const int nl = p.n_levels[t];
   const int32_t* lo = p.level_off + (long long)t * (TRACE_TREE_MAX_LEVELS + 1);
 
+  const float *Wz = w.Wz, *Wr = w.Wr, *Wh = w.Wh, *Uz = w.Uz, *Ur = w.Ur, *Uh = w.Uh;
+  auto stage = [&](const float* a0, const float* a1, const float* a2, const float* b0, const float* b1,
+                   const float* b2) {
+    if (!LDS) {
+      Wz = a0; Wr = a1; Wh = a2; Uz = b0; Ur = b1; Uh = b2;
+      return;
+    }
+    __syncthreads();
+    const int nw = F * Hd, nu = Hd * Hd;
+    float* d = wlds;
+    const float* srcs[6] = {a0, a1, a2, b0, b1, b2};
+    for (int k = 0; k < 6; ++k) {
+      const int n = k < 3 ? nw : nu;
+      for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(d + i) = *reinterpret_cast<const float4*>(srcs[k] + i);
+      d += n;
+    }
+    Wz = wlds; Wr = Wz + nw; Wh = Wr + nw; Uz = Wh + nw; Ur = Uz + nu; Uh = Ur + nu;
+    __syncthreads();
+  };
+  stage(w.Wz, w.Wr, w.Wh, w.Uz, w.Ur, w.Uh);
+
   // ---- bottom-up, leaves (cluster_tree.py:289-292)
   {
     const int v0 = lo[0], cnt = (lo[1] - lo[0]) * Hd;
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
       const float* xv = x + v * ldx;
-      float z = sigmoidf_(dot_col(w.Wz, Hd, j, xv, F));
-      float c = tanhf(dot_col(w.Wh, Hd, j, xv, F));
+      float z = sigmoidf_(dot_col(Wz, Hd, j, xv, F));
+      float c = tanhf(dot_col(Wh, Hd, j, xv, F));
       h[v * ldh + j] = (1.0f - z) * c;
     }
   }
@@ -260,11 +293,11 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
     // phase A: fa_g[v][j] = sum_c sigmoid(Wr x + Ur h_c + br)[j] * h_c[j]
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
-      const float a = dot_col(w.Wr, Hd, j, x + v * ldx, F) + w.br[j];
+      const float a = dot_col(Wr, Hd, j, x + v * ldx, F) + w.br[j];
       float fa = 0.f;
       for (int ci = p.child_off[v]; ci < p.child_off[v + 1]; ++ci) {
         const float* hc = h + (long long)p.child_idx[ci] * ldh;
-        fa += sigmoidf_(a + dot_col(w.Ur, Hd, j, hc, Hd)) * hc[j];
+        fa += sigmoidf_(a + dot_col(Ur, Hd, j, hc, Hd)) * hc[j];
       }
       ws[v * ldh + j] = fa;
     }
@@ -274,21 +307,22 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
       const float* xv = x + v * ldx;
-      float az = dot_col(w.Wz, Hd, j, xv, F) + w.bz[j];
+      float az = dot_col(Wz, Hd, j, xv, F) + w.bz[j];
       float hs = 0.f;
       for (int ci = p.child_off[v]; ci < p.child_off[v + 1]; ++ci) {
         const float* hc = h + (long long)p.child_idx[ci] * ldh;
-        az += dot_col(w.Uz, Hd, j, hc, Hd);
+        az += dot_col(Uz, Hd, j, hc, Hd);
         hs += hc[j];
       }
       const float z = sigmoidf_(az);
-      const float c = tanhf(dot_col(w.Wh, Hd, j, xv, F) + dot_col(w.Uh, Hd, j, ws + v * ldh, Hd));
+      const float c = tanhf(dot_col(Wh, Hd, j, xv, F) + dot_col(Uh, Hd, j, ws + v * ldh, Hd));
       h[v * ldh + j] = z * hs + (1.0f - z) * c;
     }
     __threadfence_block();
     __syncthreads();
   }
   // ---- top-down (cluster_tree.py:189-200, 326-330): roots copy h
+  stage(w.Wzd, w.Wrd, w.Whd, w.Uzd, w.Urd, w.Uhd);
   {
     const int v0 = lo[nl - 1], cnt = (lo[nl] - lo[nl - 1]) * Hd;
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
@@ -305,7 +339,7 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
       const int v = v0 + idx / Hd, j = idx % Hd;
       const int f = p.parent[v];
       const float* hf = hd + (long long)f * ldh;
-      float r = sigmoidf_(dot_col(w.Wrd, Hd, j, x + v * ldx, F) + dot_col(w.Urd, Hd, j, hf, Hd) + w.brd[j]);
+      float r = sigmoidf_(dot_col(Wr, Hd, j, x + v * ldx, F) + dot_col(Ur, Hd, j, hf, Hd) + w.brd[j]);
       ws[v * ldh + j] = r * hf[j];
     }
     __threadfence_block();
@@ -315,8 +349,8 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
       const int f = p.parent[v];
       const float* hf = hd + (long long)f * ldh;
       const float* xv = x + v * ldx;
-      float z = sigmoidf_(dot_col(w.Wzd, Hd, j, xv, F) + dot_col(w.Uzd, Hd, j, hf, Hd) + w.bzd[j]);
-      float c = tanhf(dot_col(w.Whd, Hd, j, xv, F) + dot_col(w.Uhd, Hd, j, ws + v * ldh, Hd));
+      float z = sigmoidf_(dot_col(Wz, Hd, j, xv, F) + dot_col(Uz, Hd, j, hf, Hd) + w.bzd[j]);
+      float c = tanhf(dot_col(Wh, Hd, j, xv, F) + dot_col(Uh, Hd, j, ws + v * ldh, Hd));
       hd[v * ldh + j] = z * hf[j] + (1.0f - z) * c;
     }
     __threadfence_block();
@@ -394,6 +428,21 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
     p.w[g] = TreeW{s.Wz, s.Wr, s.Wh, s.Uz, s.Ur, s.Uh, s.bz, s.br,
                    s.Wzd, s.Wrd, s.Whd, s.Uzd, s.Urd, s.Uhd, s.bzd, s.brd};
   }
-  hipLaunchKernelGGL(tree_gru_kernel, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
+  TRACE_REQUIRE(F % 4 == 0 && Hd % 4 == 0, "tree_gru: F and Hd must be multiples of 4");
+  TRACE_REQUIRE((((uintptr_t)x | (uintptr_t)h | (uintptr_t)hd | (uintptr_t)workspace) & 15) == 0,
+                "tree_gru: x/h/hd/workspace must be 16-byte aligned");
+  const size_t lds = (size_t)(3 * F * Hd + 3 * Hd * Hd) * sizeof(float);
+  if (lds <= 128 * 1024) {
+    static bool attr_set = false;  // raise the dynamic-LDS limit once (idempotent)
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(tree_gru_kernel<true>, dim3(n_trees, n_groups), dim3(256), lds, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(tree_gru_kernel<false>, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
+  }
   return check_launch("tree_gru");
 }

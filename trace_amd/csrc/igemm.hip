@@ -50,6 +50,11 @@ struct IgemmParams {
   float alpha;
   int epi;
   int tiles_m, tiles_n;
+  int m_fast;        // 1: position tile index fastest (weight-streaming shapes: few position tiles)
+  int ksplit, ks_per;  // split-K: blockIdx.y = K slice of ks_per K-steps, raw f32 partials to `partial`
+  float* partial;    // [ksplit][M][Cout] f32
+  void* ws;          // caller workspace for split-K (may be null)
+  size_t ws_bytes;
 };
 
 constexpr int BK = 64;
@@ -81,8 +86,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
-  const int tile_n = bid % p.tiles_n;  // cout tile fastest: a position tile's inputs stay hot
-  const int tile_m = bid / p.tiles_n;
+  // default: cout tile fastest (a position tile's inputs stay hot in L2); weight-streaming shapes
+  // (few position tiles, huge K) flip it so the tiles sharing a weight panel run side by side.
+  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
+  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
   const int cout0 = tile_n * TC;
   const int pos0 = tile_m * TP;
 
@@ -115,20 +122,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
       x_w0[i] = 0;
     }
   }
+  // K range of this block (split-K slices along blockIdx.y)
+  const int ksteps_all = (p.Ktot + BK - 1) / BK;
+  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
   // running tap state of this thread's K piece
-  int kc = kseg * 8;  // channel offset inside the current tap run
-  int ta = 0, tb = 0, tcw = 0;
-  while (kc >= p.Crun) {
-    kc -= p.Crun;
-    if (++tcw == p.kw) {
-      tcw = 0;
-      if (++tb == p.kh) {
-        tb = 0;
-        ++ta;
-      }
-    }
+  int klin = ks_begin * BK + kseg * 8;
+  int kc, ta, tb, tcw;
+  {
+    const int tap = klin / p.Crun;
+    kc = klin - tap * p.Crun;  // channel offset inside the current tap run
+    tcw = tap % p.kw;
+    const int t2 = tap / p.kw;
+    tb = t2 % p.kh;
+    ta = t2 / p.kh;
   }
-  int klin = kseg * 8;
 
   uint4 xr[WN], wr[WM];
   auto load_tiles = [&]() {
@@ -182,7 +190,6 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int ksteps = (p.Ktot + BK - 1) / BK;
   load_tiles();
   store_tiles(0);
   __syncthreads();
@@ -217,6 +224,23 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
     }
   }
 
+  // ---- split-K: raw partial sums, the epilogue runs in igemm_splitk_reduce_kernel
+  if (p.ksplit > 1) {
+    float* slab = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int c = cout0 + wm * (16 * WM) + i * 16 + fq * 4;
+        if (c >= p.Cout) continue;
+        *reinterpret_cast<float4*>(slab + (long long)m * p.Cout + c) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
   // ---- epilogue: D[row = cout (fq*4+r)][col = position fr]
   const bool relu = p.epi & TRACE_EPI_RELU;
   const bool leaky = p.epi & TRACE_EPI_LEAKY;
@@ -277,6 +301,57 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
   }
 }
 
+// Sum the split-K slabs in slice order (deterministic) and apply the epilogue.
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p) {
+  const int cq = p.Cout >> 2;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.M * cq) return;
+  const int m = (int)(idx / cq), c = (int)(idx % cq) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.ksplit; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(p.partial + ((long long)z * p.M + m) * p.Cout + c);
+    v[0] += t.x;
+    v[1] += t.y;
+    v[2] += t.z;
+    v[3] += t.w;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
+    v[0] += bv.x;
+    v[1] += bv.y;
+    v[2] += bv.z;
+    v[3] += bv.w;
+  }
+  const long long o = (long long)m * p.ldo + c;
+  auto add_res = [&]() {
+    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
+    v[0] += __uint_as_float(rv.x << 16);
+    v[1] += __uint_as_float(rv.x & 0xffff0000u);
+    v[2] += __uint_as_float(rv.y << 16);
+    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+  };
+  if ((p.epi & TRACE_EPI_RESIDUAL) && p.res) add_res();
+  if (p.epi & TRACE_EPI_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  }
+  if (p.epi & TRACE_EPI_LEAKY) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+  }
+  if ((p.epi & TRACE_EPI_RES_POST) && p.res) add_res();
+  if (p.epi & TRACE_EPI_OUT_F32) {
+    *reinterpret_cast<float4*>((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 ov;
+    ov.x = pack_bf16x2(v[0], v[1]);
+    ov.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>((uint16_t*)p.out + o) = ov;
+  }
+}
+
 template <int WM, int WN>
 static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
   constexpr int TC = 32 * WM, TP = 32 * WN;
@@ -288,7 +363,29 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
     return 1;
   }
   size_t lds = 2 * (size_t)(TC + TP) * 128;
-  hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), dim3((unsigned)nblk, 1, batch), dim3(256), lds, s, p);
+  const int ksteps = ceil_div(p.Ktot, BK);
+  p.m_fast = (p.tiles_m <= 4 && ksteps >= 64) ? 1 : 0;
+  // split-K when the tile grid cannot fill 256 CUs and K is deep (weight-streaming FC layers,
+  // single-clip convs): slices write f32 slabs to the caller's workspace, a second launch reduces.
+  p.ksplit = 1;
+  p.ks_per = ksteps;
+  if (batch == 1 && p.ws && nblk < 256 && ksteps >= 8) {
+    long long want = (768 + nblk - 1) / nblk;
+    long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
+    long long ks = want;
+    if (ks > ksteps / 4) ks = ksteps / 4;
+    if (ks > cap_ws) ks = cap_ws;
+    if (ks > 1) {
+      p.ks_per = ceil_div(ksteps, ks);
+      p.ksplit = ceil_div(ksteps, p.ks_per);
+      p.partial = (float*)p.ws;
+    }
+  }
+  hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), dim3((unsigned)nblk, p.ksplit, batch), dim3(256), lds, s, p);
+  if (p.ksplit > 1) {
+    long long n4 = (long long)p.M * (p.Cout >> 2);
+    hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+  }
   return check_launch("igemm_bf16");
 }
 
@@ -297,6 +394,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
   // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
   auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
   if (p.Cout <= 64) return launch_cfg<2, 4>(p, batch, s);        // 64 couts x 128 positions
+  if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) return launch_cfg<4, 2>(p, batch, s);  // weight streaming + split-K
   if (blocks(128, 128) >= 512) return launch_cfg<4, 4>(p, batch, s);
   if (blocks(128, 64) >= 384) return launch_cfg<4, 2>(p, batch, s);
   return launch_cfg<2, 2>(p, batch, s);                           // 64 x 64: small problems
@@ -310,7 +408,8 @@ extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi
                                        const uint16_t* w, const float* bias, int Cout, int kt,
                                        int kh, int kw, int st, int sh, int sw, int pt, int ph,
                                        int pw, int dt, int dh, int dw, const uint16_t* residual,
-                                       int epilogue, void* out, trace_stream_t stream) {
+                                       int epilogue, void* out, void* workspace,
+                                       size_t workspace_bytes, trace_stream_t stream) {
   TRACE_REQUIRE(N >= 0 && Ti > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3d: bad shape");
   TRACE_REQUIRE(Cin % 8 == 0, "conv3d: Cin=%d must be a multiple of 8", Cin);
   TRACE_REQUIRE(Cout % 8 == 0, "conv3d: Cout=%d must be a multiple of 8", Cout);
@@ -348,6 +447,8 @@ extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi
   p.ldo = Cout;
   p.alpha = 1.0f;
   p.epi = epilogue;
+  p.ws = ((uintptr_t)workspace & 15) ? nullptr : workspace;
+  p.ws_bytes = workspace_bytes;
   return launch_igemm(p, 1, (hipStream_t)stream);
 }
 
@@ -393,8 +494,8 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
 extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda,
                                   int ldb, int ldc, int batch, long long strideA, long long strideB,
                                   long long strideC, float alpha, const float* bias,
-                                  const uint16_t* residual, int epilogue, void* C,
-                                  trace_stream_t stream) {
+                                  const uint16_t* residual, int epilogue, void* C, void* workspace,
+                                  size_t workspace_bytes, trace_stream_t stream) {
   TRACE_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   if (M == 0 || N == 0 || batch == 0) return 0;
   TRACE_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm: K, lda, ldb must be multiples of 8");
@@ -428,5 +529,8 @@ extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, 
   p.bs_in = strideA; p.bs_w = strideB; p.bs_out = strideC;
   p.alpha = alpha;
   p.epi = epilogue;
+  // split-K partials are dense [M][N]: only for the plain (non-batched) case
+  p.ws = (batch == 1 && !((uintptr_t)workspace & 15)) ? workspace : nullptr;
+  p.ws_bytes = workspace_bytes;
   return launch_igemm(p, batch, (hipStream_t)stream);
 }

@@ -18,6 +18,21 @@ EPI_OUT_F32 = 4
 IGEMM_TRACE = None
 
 
+_WS = {}
+WORKSPACE_BYTES = 64 << 20
+
+
+def workspace(device):
+    """Per-device split-K scratch handed to the igemm entry points (the library allocates nothing).
+    One buffer per device: calls that use it must be ordered on one stream."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty((WORKSPACE_BYTES,), dtype=torch.uint8, device=torch.device("cuda", key))
+        _WS[key] = ws
+    return ws
+
+
 class _span:
     def __init__(self, flops):
         self.flops = flops
@@ -96,11 +111,12 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
             raise RuntimeError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(out.shape)))
     if bias is not None:
         bias = _f32(bias, "bias")
+    ws = workspace(x.device)
     with torch.cuda.device(x.device), _span(2.0 * out.numel() * kt * kh * kw * Cin):
         L.check(L.lib().trace_conv3d_igemm_bf16(
             L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
             stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
-            L.ptr(residual), epi, L.ptr(out), L.stream()), "conv3d_igemm")
+            L.ptr(residual), epi, L.ptr(out), L.ptr(ws), ws.numel(), L.stream()), "conv3d_igemm")
     return out
 
 
@@ -187,9 +203,11 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
         epi |= EPI_RES_POST if residual_post else EPI_RESIDUAL
     if bias is not None:
         bias = _f32(bias, "bias")
+    ws = workspace(A.device)
     with torch.cuda.device(A.device), _span(2.0 * b * M * N * K):
         L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
-                                           L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.stream()),
+                                           L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.ptr(ws), ws.numel(),
+                                           L.stream()),
                 "gemm_bf16_nt")
     return out
 
