@@ -2,6 +2,11 @@
 
 PyTorch is used for device memory and streams only; every op below is one call
 through the C-ABI (include/trace_amd.h).  Tensors must live on the GPU.
+
+Launch plans: the I3D backbone is ~130 launches of fixed shape per batch.  `record()` captures the
+(C entry point, argument tuple) of every launch made inside it together with the tensors they touch;
+`Plan.replay()` re-issues exactly those calls on the current stream with no Python/torch work per
+launch (same role as a HIP graph, but launch-by-launch so the per-launch event trace still works).
 """
 import ctypes
 
@@ -17,15 +22,15 @@ EPI_OUT_F32 = 4
 # events on the launch stream and (start, end, algorithmic_flops) is appended: bench.py's roofline leg.
 IGEMM_TRACE = None
 
-
 _WS = {}
 WORKSPACE_BYTES = 64 << 20
+_RECORDING = None
 
 
 def workspace(device):
     """Per-device split-K scratch handed to the igemm entry points (the library allocates nothing).
     One buffer per device: calls that use it must be ordered on one stream."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    key = device.index if device.index is not None else torch.cuda.current_device()
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty((WORKSPACE_BYTES,), dtype=torch.uint8, device=torch.device("cuda", key))
@@ -33,7 +38,91 @@ def workspace(device):
     return ws
 
 
+def _raw_stream(index):
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
+def _launch(name, fn, args, dev, flops=None):
+    """One C-ABI launch on the current stream of `dev` (args exclude the trailing stream)."""
+    idx = dev.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        with torch.cuda.device(idx):
+            return _launch(name, fn, args, torch.device("cuda", idx), flops)
+    stream = _raw_stream(idx)
+    if IGEMM_TRACE is not None and flops is not None:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args, stream)
+        e.record()
+        IGEMM_TRACE.append((s, e, flops))
+    else:
+        rc = fn(*args, stream)
+    if rc != 0:
+        L.check(rc, name)
+    if _RECORDING is not None:
+        _RECORDING.calls.append((fn, args, name, flops))
+
+
+class Plan:
+    """A recorded launch sequence (see module docstring)."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+        self.out = None
+        self.device_index = None
+
+    def replay(self):
+        stream = _raw_stream(self.device_index)
+        trace = IGEMM_TRACE
+        for fn, args, name, flops in self.calls:
+            if trace is not None and flops is not None:
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                rc = fn(*args, stream)
+                e.record()
+                trace.append((s, e, flops))
+            else:
+                rc = fn(*args, stream)
+            if rc != 0:
+                L.check(rc, name)
+        return self.out
+
+
+class record:
+    """Context manager: `with record(device) as plan: out = f(...)`; tensors created by torch inside
+    stay alive as long as the plan does (torch's caching allocator cannot hand them out again)."""
+
+    def __init__(self, device, keep=()):
+        self.plan = Plan()
+        self.plan.device_index = device.index if device.index is not None else torch.cuda.current_device()
+        self.plan.keep.extend(keep)
+
+    def __enter__(self):
+        global _RECORDING
+        if _RECORDING is not None:
+            raise RuntimeError("nested ops.record()")
+        _RECORDING = self.plan
+        return self.plan
+
+    def __exit__(self, *a):
+        global _RECORDING
+        _RECORDING = None
+        return False
+
+
+def _keep(*tensors):
+    if _RECORDING is not None:
+        _RECORDING.keep.extend(t for t in tensors if t is not None)
+
+
 class _span:
+    """Brackets one igemm launch with events on the launch stream when IGEMM_TRACE is a list."""
+
     def __init__(self, flops):
         self.flops = flops
 
@@ -49,6 +138,7 @@ class _span:
             self.e.record()
             IGEMM_TRACE.append((self.s, self.e, self.flops))
         return False
+
 
 TREE_MAX_LEVELS = 12
 
