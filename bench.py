@@ -13,7 +13,8 @@ the timed region, as the sweep does.  Inputs are resident in HBM 
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     - dominant kernel (bf16 MFMA implicit-GEMM family): algorithmic FLOPs / launch time,
-                 measured with events on the launch stream inside the timed steps
+                 measured with events on the launch stream over the same K steps re-run launch by launch
+                 right after the timed region (the timed steps replay the backbone from a HIP graph)
   cpu_baseline - the CPU oracle (a port of the reference path) timed on the host cores (rank 0, N=1)
 """
 import argparse
@@ -93,6 +94,7 @@ def main():
     model.eval()
     sd_cpu = None
     model.to(dev)
+    model.graph_backbone = True
     calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
     model.Prd_RCNN.calibrate_bn(calib.to(dev))       # setup only: sane activations for random weights
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -109,11 +111,12 @@ def main():
 
     for _ in range(args.warmup):
         outs = step()
+    # the clips stay resident in the buffer the captured backbone graph reads (no per-step copy)
+    frames = model.Prd_RCNN.graph_clip_buffer(frames, in_ntchw=True)
+    outs = step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    trace = None if args.no_trace else []
-    ops.IGEMM_TRACE = trace
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -122,7 +125,16 @@ def main():
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ops.IGEMM_TRACE = None
+    # roofline leg: the same K steps with every igemm launch bracketed by events on the launch stream
+    # (launch by launch, i.e. without the graph replay, whose nodes cannot carry events)
+    trace = None
+    if rank == 0 and not args.no_trace:
+        trace = []
+        ops.IGEMM_TRACE = trace
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ops.IGEMM_TRACE = None
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -50,7 +50,10 @@ for name,cin,T,H,W,cout,k,s,p,d,cnt in L:
     y = ops.conv3d(x,w,b,k,s,p,d,relu=True)
     ms = bench(lambda: ops.conv3d(x,w,b,k,s,p,d,relu=True))
     fl = 2.0*y.numel()*k[0]*k[1]*k[2]*cin
-    print('%-22s M=%7d N=%5d K=%5d  %7.3f ms x%2d  %7.1f TF/s' % (name, y.numel()//cout, cout, k[0]*k[1]*k[2]*cin, ms, cnt, fl/ms/1e9))
+    by = 2.0*(x.numel()+y.numel()+w.numel())
+    tmin = max(fl/2.5e15, by/8e12)*1e3
+    print('%-22s M=%7d N=%5d K=%5d  %7.3f ms x%2d  %7.1f TF/s  %6.1f MB  roof %6.3f ms (%s) frac %.2f' % (name, y.numel()//cout, cout, k[0]*k[1]*k[2]*cin, ms, cnt, fl/ms/1e9, by/1e6, tmin, 'mfma' if fl/2.5e15>by/8e12 else 'hbm', tmin/ms))
+    totmin = globals().get('totmin',0)+tmin*cnt
     tot += ms*cnt; totf += fl*cnt
 # stem
 xp = torch.randn((B,36,230,230,4),device=dev).bfloat16(); w=(torch.randn((64,5*7*8*4),device=dev)*0.05).bfloat16(); b=torch.randn((64,),device=dev)
@@ -65,4 +68,4 @@ for (nq,nkv,c,cnt) in ((3136,784,256,2),(784,196,512,3)):
     ms2 = bench(lambda: ops.gemm_nt(pw,gt))
     fl = 2.0*B*nq*nkv*c
     print('NL qk %dx%dx%d %7.3f ms %7.1f TF/s | pv %7.3f ms %7.1f TF/s  x%d' % (nq,nkv,c,ms1,fl/ms1/1e9,ms2,fl/ms2/1e9,cnt)); tot+=(ms1+ms2)*cnt; totf+=2*fl*cnt
-print('sum conv+gemm ms', tot, 'GFLOP', totf/1e9, 'avg TF/s', totf/tot/1e9)
+print('roofline-min ms (convs only)', totmin); print('sum conv+gemm ms', tot, 'GFLOP', totf/1e9, 'avg TF/s', totf/tot/1e9)

@@ -120,3 +120,20 @@ def test_i3d_output_shapes_at_baseline_sizes():
     # (N,T,C,H,W) entry layout (model_builder_rel.py:688,978) gives the same result
     yt = m.forward_ndhwc(clip.permute(0, 2, 1, 3, 4).contiguous(), in_ntchw=True)
     assert torch.equal(yt, y)
+
+
+def test_i3d_graph_replay_equals_eager():
+    """The HIP-graph replay of the backbone launches is bit-identical to the eager launches, also when
+    the caller hands in a different buffer on a later call (copied into the captured input)."""
+    m = make_model().to(DEV)
+    g = torch.Generator().manual_seed(4)
+    a = (torch.randn((2, 3, 16, 64, 64), generator=g) * 50).to(DEV)
+    b = (torch.randn((2, 3, 16, 64, 64), generator=g) * 50).to(DEV)
+    ea, eb = m.forward_ndhwc(a).clone(), m.forward_ndhwc(b).clone()
+    ga = m.forward_ndhwc_graphed(a).clone()
+    gb = m.forward_ndhwc_graphed(b).clone()
+    ga2 = m.forward_ndhwc_graphed(a).clone()
+    assert torch.equal(ga, ea) and torch.equal(gb, eb) and torch.equal(ga2, ea)
+    buf = m.graph_clip_buffer(a)
+    buf.copy_(b)
+    assert torch.equal(m.forward_ndhwc_graphed(buf), eb)

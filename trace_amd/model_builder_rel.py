@@ -52,6 +52,34 @@ def _bf(x):
     return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
 
 
+class _Upload:
+    """All per-step host arrays (roi lists, forest CSR arrays, pair indices) travel in ONE pinned
+    staging buffer and one stream-ordered copy: the reference uploads each list with a blocking
+    `torch.from_numpy(..).cuda()` (model_builder_rel.py:1389, cluster_tree.py:214,730)."""
+
+    _DT = {np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+
+    def __init__(self):
+        self.items = []
+        self.nbytes = 0
+
+    def add(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype not in self._DT:
+            raise TypeError("upload: unsupported dtype %s" % a.dtype)
+        self.items.append((self.nbytes, a))
+        self.nbytes = (self.nbytes + a.nbytes + 255) // 256 * 256
+        return len(self.items) - 1
+
+    def commit(self, dev):
+        host = torch.empty((max(self.nbytes, 256),), dtype=torch.uint8, pin_memory=True)
+        hv = host.numpy()
+        for off, a in self.items:
+            hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        d = host.to(dev, non_blocking=True)
+        return [d[off:off + a.nbytes].view(self._DT[a.dtype]).view(a.shape) for off, a in self.items]
+
+
 class Generalized_RCNN(nn.Module):
     def __init__(self, cfg: TraceConfig = None):
         super().__init__()
@@ -108,6 +136,9 @@ class Generalized_RCNN(nn.Module):
         self.cem_Box_Outs = fast_rcnn_outputs(D, cfg, with_bbox=False)
         self.cem_Box_Outs.load_state_dict({k: v for k, v in self.Box_Outs.state_dict().items() if "cls_score" in k})
         self._pk = {}
+        # replay the I3D launches from a HIP graph (one graph per clip-batch shape); serving loops with a
+        # fixed batch shape switch this on, shape-varying callers leave it off
+        self.graph_backbone = False
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -240,7 +271,8 @@ class Generalized_RCNN(nn.Module):
         C = cfg.CONV_BODY_DIM
         ct3 = self.cluster_tree3d
         # ---- I3D backbone: launched first, the host work below overlaps it (:978-981)
-        tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True)          # (B,T',h,w,2048) bf16
+        i3d = self.Prd_RCNN.forward_ndhwc_graphed if self.graph_backbone else self.Prd_RCNN.forward_ndhwc
+        tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
         Tn = tmaps.shape[1]
         tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
         blob = self._nhwc(blob_conv)
@@ -286,17 +318,26 @@ class Generalized_RCNN(nn.Module):
             pairs.append((s, o, ct.lca(tree, s, o) - n, union))
         moff = np.concatenate([[0], np.cumsum(m_list)]).astype(np.int64)
         Mtot = int(moff[-1])
-        forest = {k: torch.from_numpy(v).to(dev) for k, v in ct.forest_arrays(trees).items()}
         node_obj = np.concatenate([np.arange(n_list[b]) + off[b] + moff[b] for b in range(B)])
         node_reg = np.concatenate([np.arange(m_list[b]) + off[b + 1] + moff[b] for b in range(B)])
-        up = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        det_all_d = up(det_all)
-        node_obj_d, node_reg_d = up(node_obj), up(node_reg)
-        X = up(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]))
-        Y = up(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]))
-        LCA = up(np.concatenate([p[2] + moff[b] for b, p in enumerate(pairs)]))
-        union_d = up(np.concatenate([p[3] for p in pairs], 0))
         poff = np.concatenate([[0], np.cumsum([len(p[0]) for p in pairs])]).astype(np.int64)
+        upl = _Upload()
+        forest_np = ct.forest_arrays(trees)
+        forest_keys = list(forest_np)
+        forest_ix = [upl.add(forest_np[k]) for k in forest_keys]
+        ix = dict(det=upl.add(det_all), node_obj=upl.add(node_obj), node_reg=upl.add(node_reg),
+                  X=upl.add(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]).astype(np.int64)),
+                  Y=upl.add(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]).astype(np.int64)),
+                  LCA=upl.add(np.concatenate([p[2] + moff[b] for b, p in enumerate(pairs)]).astype(np.int64)),
+                  union=upl.add(np.concatenate([p[3] for p in pairs], 0)),
+                  t_obj=upl.add(np.concatenate(t_obj, 0)), t_reg=upl.add(np.concatenate(t_reg, 0)),
+                  reg=upl.add(np.concatenate(reg_rois, 0)),
+                  pclip=upl.add(np.repeat(np.arange(B), np.diff(poff)).astype(np.int64)),
+                  poff=upl.add(poff[:-1].astype(np.int64)))
+        dv = upl.commit(dev)
+        forest = {k: dv[i] for k, i in zip(forest_keys, forest_ix)}
+        det_all_d, node_obj_d, node_reg_d = dv[ix["det"]], dv[ix["node_obj"]], dv[ix["node_reg"]]
+        X, Y, LCA, union_d = dv[ix["X"]], dv[ix["Y"]], dv[ix["LCA"]], dv[ix["union"]]
 
         # ---- detection heads on the key frame (:742-743, :938-952)
         pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
@@ -315,8 +356,7 @@ class Generalized_RCNN(nn.Module):
         det_feat = ori + self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True)  # :945-946
 
         # ---- cluster_tree3d: temporal object features (:158-201)
-        def temporal_branch(roi_list, cur_feat, fc, q_s_l, q_o_l, val, tag):
-            rois_d = up(np.concatenate(roi_list, 0))
+        def temporal_branch(rois_d, cur_feat, fc, q_s_l, q_o_l, val, tag):
             tvec = ops.roi_align_avg_nhwc(tm_flat, rois_d, cfg.REL_SPATIAL_SCALE, ps, 0)  # ROIAlign + box_head3d.py:60-61
             tfeat = self._gemm(tvec, tag + "_fc2", [fc.fc2], relu=True, out_f32=True)    # (K,D), (obj,t) order
             k = cur_feat.shape[0]
@@ -327,14 +367,14 @@ class Generalized_RCNN(nn.Module):
             v = F.relu(F.layer_norm(v, (v.shape[-1],), val[1].weight, val[1].bias, val[1].eps))
             return cur_feat + self._gemm(v, tag + "_v3", [val[3]], out_f32=True)
 
-        obj_agg = temporal_branch(t_obj, det_feat, ct3.temporal_obj_fc, ct3.temporal_obj_atten_q_s,
+        obj_agg = temporal_branch(dv[ix["t_obj"]], det_feat, ct3.temporal_obj_fc, ct3.temporal_obj_atten_q_s,
                                   ct3.temporal_obj_atten_q_o, ct3.temporal_obj_feat_val, "tobj")
         # ---- regions (:222-305)
-        reg_rois_d = up(np.concatenate(reg_rois, 0))
+        reg_rois_d = dv[ix["reg"]]
         reg_map = ops.roi_align_nhwc(fmap, reg_rois_d, cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
         r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
         reg_feat = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True)
-        reg_agg = temporal_branch(t_reg, reg_feat, ct3.temporal_r_fc, ct3.temporal_r_atten_q_s,
+        reg_agg = temporal_branch(dv[ix["t_reg"]], reg_feat, ct3.temporal_r_fc, ct3.temporal_r_atten_q_s,
                                   ct3.temporal_r_atten_q_o, ct3.temporal_r_feat_val, "treg")
         # ---- tree message passing (:307-330)
         o2c = self._gemm(F.relu(obj_agg), "o2c", [ct3.o2c[1]], out_f32=True)
@@ -387,7 +427,13 @@ class Generalized_RCNN(nn.Module):
             logits = logits + self.freq_bias.rel_index_with_labels(torch.stack((lab[X], lab[Y]), 1))  # :1064,:1075
         prd = torch.sigmoid(logits) if cfg.MULTI_RELATION else F.softmax(logits, dim=1)   # :1083 / :1090
 
-        # ---- per-clip return dicts (:1162-1182)
+        # ---- per-clip return dicts (:1162-1182); gathers and the ranking run once over all clips
+        sbj_lab_all, obj_lab_all = det_labels[X], det_labels[Y]
+        sbj_sc_all, obj_sc_all = det_scores[X], det_scores[Y]
+        top = None
+        if topk:
+            top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
+                                             dv[ix["pclip"]], poff, dv[ix["poff"]], topk, prd_k)
         outs = []
         for b in range(B):
             s, o = pairs[b][0], pairs[b][1]
@@ -397,16 +443,38 @@ class Generalized_RCNN(nn.Module):
             ol = slice(int(off[b]), int(off[b + 1]))
             d = dict(sbj_rois=rois_b[s], obj_rois=rois_b[o], det_rois=rois_b, sbj_inds=s, obj_inds=o,
                      det_labels=det_labels[ol], det_scores=det_scores[ol],
-                     sbj_labels=det_labels[ol][up(s)], obj_labels=det_labels[ol][up(o)],
-                     sbj_scores=det_scores[ol][up(s)], obj_scores=det_scores[ol][up(o)],
+                     sbj_labels=sbj_lab_all[sl], obj_labels=obj_lab_all[sl],
+                     sbj_scores=sbj_sc_all[sl], obj_scores=obj_sc_all[sl],
                      msp_det_scores=obj_score[ol], prd_scores=prd[sl], prd_ttl_scores=prd[sl])
-            if topk:
-                d.update(self.topk_triplets(d, topk, prd_k))
+            if top is not None:
+                k = min(topk, (int(poff[b + 1]) - int(poff[b])) * min(prd_k, prd.shape[1]))
+                d.update({name: v[b, :k] for name, v in top.items()})
             outs.append(d)
         self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
                            q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
                            logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)
         return outs
+
+    @staticmethod
+    def topk_triplets_batched(prd, sbj_sc, obj_sc, sbj_lab, obj_lab, pclip, poff, poff_d, topk, prd_k=1):
+        """`topk_triplets` for every clip at once: the ragged per-clip candidate lists are scattered into
+        a (B, Pmax*prd_k) matrix padded with -1 (scores are products of probabilities, >= 0) and ranked
+        by one top-k.  Returns (B, topk) tensors; clip b's first min(topk, P_b*prd_k) columns are valid."""
+        B = len(poff) - 1
+        kk = min(prd_k, prd.shape[1])
+        sc, lab = torch.topk(prd, kk, dim=1)                       # (Ptot, kk)
+        spo = (sbj_sc * obj_sc)[:, None] * sc
+        pmax = int(np.max(np.diff(poff))) if B else 0
+        local = torch.arange(prd.shape[0], device=prd.device) - poff_d[pclip]
+        dense = torch.full((B, pmax * kk), -1.0, dtype=spo.dtype, device=prd.device)
+        col = local[:, None] * kk + torch.arange(kk, device=prd.device)[None, :]
+        dense[pclip[:, None].expand(-1, kk), col] = spo
+        k = min(topk, pmax * kk)
+        top, idx = torch.topk(dense, k, dim=1)                     # ties: torch.topk order, as topk_triplets
+        pair = idx // kk + poff_d[:, None]
+        pair = pair.clamp_(max=prd.shape[0] - 1)
+        return dict(top_scores=top, top_pair=idx // kk, top_prd=lab.reshape(-1)[(pair * kk + idx % kk)],
+                    top_sbj=sbj_lab[pair], top_obj=obj_lab[pair])
 
     @staticmethod
     def topk_triplets(d, topk, prd_k=1):
