@@ -94,7 +94,7 @@ def main():
     model.eval()
     sd_cpu = None
     model.to(dev)
-    model.graph_backbone = True
+    model.graph_step = True     # serving mode: the whole step replays from one HIP graph per step signature
     calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
     model.Prd_RCNN.calibrate_bn(calib.to(dev))       # setup only: sane activations for random weights
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -111,8 +111,8 @@ def main():
 
     for _ in range(args.warmup):
         outs = step()
-    # the clips stay resident in the buffer the captured backbone graph reads (no per-step copy)
-    frames = model.Prd_RCNN.graph_clip_buffer(frames, in_ntchw=True)
+    # the inputs stay resident in the buffers the captured step graph reads (no per-step copy)
+    frames, blob, feat = model.step_buffers()
     outs = step()
     torch.cuda.synchronize()
     if dist:

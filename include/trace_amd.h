@@ -204,6 +204,13 @@ int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
                        void* workspace, size_t workspace_bytes,
                        trace_stream_t stream);
 
+/* Launch-configuration override for the three entry points above, for the calling thread:
+ * tile 1..4 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128), nst = LDS ring depth 2..4,
+ * ksplit = split-K factor; 0 = let the library choose (the default).  No counterpart in the
+ * reference (cuDNN picks its own algorithm there); used by tools/tune_igemm.py and the tests that
+ * cover every tile shape. */
+int trace_igemm_tune(int tile, int nst, int ksplit);
+
 /* bf16 (rows, cols) -> bf16 (cols, rows) per batch, output row stride ld_out
  * (>= rows) and batch stride out_batch_stride; used to form g^T for the
  * non-local block without leaving channels-last. */

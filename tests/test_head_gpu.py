@@ -90,3 +90,29 @@ def test_head_matches_oracle(setup, B, T, n):
         assert len(want & got) >= 0.99 * len(want), (b, len(want & got), len(want))
         off += nb
         poff += P
+
+
+def test_step_graph_replay_equals_eager(setup):
+    """The whole-step HIP graph (graph_step) returns exactly what the eager launches return, for new
+    box lists of the same step signature and after a signature change (re-capture)."""
+    from trace_amd.synthetic import make_inputs
+    m = setup
+    m.to(DEV)
+    frames, blob, feat, rois = make_inputs(2, 8, 6, 224, seed=11)
+    frames2, blob2, feat2, rois2 = make_inputs(2, 8, 6, 224, seed=12)
+    cases = [(frames, blob, feat, rois), (frames2, blob2, feat2, rois2), (frames, blob, feat, [rois[0], rois[1][:4]])]
+    keys = ("prd_scores", "det_labels", "msp_det_scores", "top_scores", "top_pair", "top_prd")
+    eager = []
+    for fr, bl, fe, ro in cases:
+        outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+        eager.append([{k: o[k].clone() for k in keys} for o in outs])
+    m.graph_step = True
+    try:
+        for rep in range(2):
+            for (fr, bl, fe, ro), want in zip(cases, eager):
+                outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+                for o, w in zip(outs, want):
+                    for k in keys:
+                        assert torch.equal(o[k], w[k]), (rep, k)
+    finally:
+        m.graph_step = False

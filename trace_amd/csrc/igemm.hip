@@ -23,6 +23,7 @@
 //     (register-staged split pipeline), one barrier per K-step;
 //   * the same kernel runs plain/batched GEMMs (1 tap, explicit row strides).
 #include "common.h"
+#include <stdlib.h>
 
 namespace trace {
 
@@ -54,6 +55,8 @@ struct IgemmParams {
   int ksplit, ks_per;  // split-K: blockIdx.y = K slice of ks_per K-steps, raw f32 partials to `partial`
   float* partial;    // [ksplit][M][Cout] f32
   void* ws;          // caller workspace for split-K (may be null)
+  int narrow;        // 1: Cout or ldo not a multiple of 8 -> 4-channel epilogue groups
+  int dense;         // 1: rows of `in` are the GEMM rows (1 tap, unit stride, no padding)
   size_t ws_bytes;
 };
 
@@ -301,6 +304,363 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 main kernel: both operands go HBM/L2 -> LDS with 16-byte LDS-DMA loads (no register staging, no
+// ds_write pass); halo / tail pieces read a zero page instead of branching around the load; the
+// XOR swizzle lives on the SOURCE address (LDS-DMA writes lane-linear) and on the fragment reads;
+// weight rows are permuted inside a 32-cout group so that a lane ends up with 8 consecutive output
+// channels of one position -> 16-byte channels-last stores / residual loads.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) const uint4 g_zero_page[16] = {};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// cout offset (inside a 32-cout group) held by MFMA row `rho` of the even/odd fragment of a pair
+__device__ __forceinline__ int perm_row(int odd, int rho) { return ((rho >> 2) << 3) + (odd << 2) + (rho & 3); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int WN, bool DENSE, int NST>
+__global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
+  static_assert(WM % 2 == 0, "cout fragments come in pairs");
+  constexpr int TC = 32 * WM;  // cout rows per block
+  constexpr int TP = 32 * WN;  // positions per block
+  constexpr int A_BYTES = TC * 128;
+  constexpr int B_BYTES = TP * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
+  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
+  const int cout0 = tile_n * TC;
+  const int pos0 = tile_m * TP;
+
+  const uint16_t* gin = p.in + (long long)blockIdx.z * p.bs_in;
+  const uint16_t* gw = p.w + (long long)blockIdx.z * p.bs_w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+
+  // ---- loader assignment: one LDS-DMA instruction of a wave fills 8 rows x 128 B; this lane owns
+  // physical chunk (lane&7) of row (lane>>3) of it, i.e. LOGICAL k-chunk (lane&7)^(lane>>3)
+  const int lrow = wave * 8 + (lane >> 3);      // row inside a 32-row round
+  const int kseg = (lane & 7) ^ (lane >> 3);    // logical 16-byte chunk of the K-step
+
+  const int ksteps_all = (p.Ktot + BK - 1) / BK;
+  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
+  int klin = ks_begin * BK + kseg * 8;
+
+  const uint16_t* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    // A-tile row (32*i + lrow) holds weight row cout0 + 32*(row>>5) + perm(row&31): the permutation is
+    // applied when fragments are READ, the tile itself is in natural cout order
+    int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
+    wp[i] = gw + (long long)row * p.ldw + klin;
+  }
+  // positions
+  const uint16_t* xp[WN];   // DENSE: running pointers
+  long long x_nbase[WN];
+  int x_t0[WN], x_h0[WN], x_w0[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    int m = pos0 + lrow + 32 * i;
+    if (DENSE) {
+      m = min(m, p.M - 1);
+      xp[i] = gin + (long long)m * p.pix + klin;
+    } else {
+      if (m < p.M) {
+        int wo = m % p.Wo;
+        int t1 = m / p.Wo;
+        int ho = t1 % p.Ho;
+        int t2 = t1 / p.Ho;
+        int to = t2 % p.To;
+        int n = t2 / p.To;
+        x_nbase[i] = (long long)n * p.in_n_stride;
+        x_t0[i] = to * p.st - p.pt;
+        x_h0[i] = ho * p.sh - p.ph;
+        x_w0[i] = wo * p.sw - p.pw;
+      } else {
+        x_nbase[i] = 0;
+        x_t0[i] = -0x40000000;
+        x_h0[i] = 0;
+        x_w0[i] = 0;
+      }
+    }
+  }
+  int kc = 0, ta = 0, tb = 0, tcw = 0;
+  if (!DENSE) {
+    const int tap = klin / p.Crun;
+    kc = klin - tap * p.Crun;
+    tcw = tap % p.kw;
+    const int t2 = tap / p.kw;
+    tb = t2 % p.kh;
+    ta = t2 / p.kh;
+  }
+
+  auto issue = [&](int stage) {
+    char* a = smem + stage * STAGE + wave * 1024;
+    char* b = a + A_BYTES;
+    const bool kvalid = klin < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) glds16(kvalid ? wp[i] : zero, a + i * 4096);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const uint16_t* src;
+      if (DENSE) {
+        src = kvalid ? xp[i] : zero;
+      } else {
+        int ti = x_t0[i] + ta * p.dt, hi = x_h0[i] + tb * p.dh, wi = x_w0[i] + tcw * p.dw;
+        bool ok = kvalid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+                  (unsigned)wi < (unsigned)p.Wi;
+        long long off = x_nbase[i] + ((long long)(ti * p.Hi + hi) * p.Wi + wi) * p.pix + kc;
+        src = ok ? gin + off : zero;
+      }
+      glds16(src, b + i * 4096);
+    }
+  };
+  auto advance = [&]() {
+    klin += BK;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) wp[i] += BK;
+    if (DENSE) {
+#pragma unroll
+      for (int i = 0; i < WN; ++i) xp[i] += BK;
+    } else {
+      kc += BK;
+      while (kc >= p.Crun) {
+        kc -= p.Crun;
+        if (++tcw == p.kw) {
+          tcw = 0;
+          if (++tb == p.kh) {
+            tb = 0;
+            ++ta;
+          }
+        }
+      }
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // A fragment i (pair q = i>>1, odd = i&1), MFMA row fr  <-  tile row wm*16*WM + q*32 + perm_row(odd, fr)
+  int a_row[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) a_row[i] = wm * (16 * WM) + (i >> 1) * 32 + perm_row(i & 1, fr);
+
+  // NST-deep LDS ring: the loads of K-step ks+NST-1 are issued at step ks (into the stage read at step
+  // ks-1), so NST-2 steps stay in flight across each barrier; the wait is a counted vmcnt (never 0 in
+  // steady state) followed by a raw s_barrier (__syncthreads() would drain the LDS-DMA queue).
+  constexpr int L = WM + WN;  // LDS-DMA instructions per thread per stage
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) {
+    if (s0 < ksteps) {
+      if (s0) advance();
+      issue(s0);
+    }
+  }
+  int cur = 0, nxt = NST - 1;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int ahead = min(NST - 2, ksteps - 1 - ks);  // K-steps issued after ks that may stay in flight
+    if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NST >= 3 && ahead == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // step ks landed for every wave; every wave is done reading step ks-1's stage
+    if (ks + NST - 1 < ksteps) {
+      advance();
+      issue(nxt);
+    }
+    const char* a = smem + cur * STAGE;
+    const char* b = a + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[WM], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + lds_off(a_row[i], s * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(b + lds_off(wn * (16 * WN) + j * 16 + fr, s * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+  }
+
+  // lane holds, for position fr of fragment j and pair q: couts cbase + q*32 + fq*8 + [0..7]
+  // (acc[2q][j] = first four, acc[2q+1][j] = last four)
+  const int cbase = cout0 + wm * (16 * WM) + fq * 8;
+  if (p.ksplit > 1) {
+    float* slab = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int q = 0; q < WM / 2; ++q) {
+        const int c = cbase + q * 32;
+        if (c >= p.Cout) continue;
+        float* o = slab + (long long)m * p.Cout + c;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[2 * q][j][0], acc[2 * q][j][1], acc[2 * q][j][2], acc[2 * q][j][3]);
+        if (c + 4 < p.Cout)
+          *reinterpret_cast<float4*>(o + 4) =
+              make_float4(acc[2 * q + 1][j][0], acc[2 * q + 1][j][1], acc[2 * q + 1][j][2], acc[2 * q + 1][j][3]);
+      }
+    }
+    return;
+  }
+  const bool relu = p.epi & TRACE_EPI_RELU;
+  const bool leaky = p.epi & TRACE_EPI_LEAKY;
+  const bool res_post = (p.epi & TRACE_EPI_RES_POST) && p.res;
+  const bool has_res = (p.epi & TRACE_EPI_RESIDUAL) && p.res;
+  const bool out_f32 = p.epi & TRACE_EPI_OUT_F32;
+  const long long obase = (long long)blockIdx.z * p.bs_out;
+  // loads use clamped (always valid) addresses so that they need no per-lane branch; only the store
+  // is predicated.  Cout % 8 == 0 is required by the host wrapper.
+  long long orow[WN];
+  bool mok[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
+    mok[j] = m < p.M;
+    orow[j] = obase + (long long)min(m, p.M - 1) * p.ldo;
+  }
+  if (p.narrow) {
+    // N or ldc not a multiple of 8 (plain GEMMs only): 4-channel groups, 8-byte accesses
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int c = cbase + (i >> 1) * 32 + (i & 1) * 4;
+      const bool cok = c < p.Cout;
+      const int cl = min(c, p.Cout - 4);
+      float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + cl);
+      const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        float v[4], rf[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_res || res_post) {
+          const uint2 rv = *reinterpret_cast<const uint2*>(p.res + orow[j] + cl);
+          rf[0] = __uint_as_float(rv.x << 16);
+          rf[1] = __uint_as_float(rv.x & 0xffff0000u);
+          rf[2] = __uint_as_float(rv.y << 16);
+          rf[3] = __uint_as_float(rv.y & 0xffff0000u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[i][j][r] * p.alpha + bv[r];
+          if (has_res) v[r] += rf[r];
+          if (relu) v[r] = fmaxf(v[r], 0.f);
+          if (leaky) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+          if (res_post) v[r] += rf[r];
+        }
+        if (mok[j] && cok) {
+          const long long o = orow[j] + c;
+          if (out_f32) {
+            *reinterpret_cast<float4*>((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 ov;
+            ov.x = pack_bf16x2(v[0], v[1]);
+            ov.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>((uint16_t*)p.out + o) = ov;
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < WM / 2; ++q) {
+    const int c = cbase + q * 32;
+    const bool cok = c < p.Cout;
+    const int cl = min(c, p.Cout - 8);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cl);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cl + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+      bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    uint4 rv[WN];
+    if (has_res || res_post) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) rv[j] = *reinterpret_cast<const uint4*>(p.res + orow[j] + cl);
+    } else {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) rv[j] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * q][j][r] * p.alpha + bv[r];
+        v[4 + r] = acc[2 * q + 1][j][r] * p.alpha + bv[4 + r];
+      }
+      const uint32_t rw[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
+      float rf[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        rf[2 * r] = __uint_as_float(rw[r] << 16);
+        rf[2 * r + 1] = __uint_as_float(rw[r] & 0xffff0000u);
+      }
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rf[r];
+      }
+      if (relu) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (leaky) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+      }
+      if (res_post) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += rf[r];
+      }
+      if (mok[j] && cok) {
+        const long long o = orow[j] + c;
+        if (out_f32) {
+          float* op = (float*)p.out + o;
+          *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          uint4 ov;
+          ov.x = pack_bf16x2(v[0], v[1]);
+          ov.y = pack_bf16x2(v[2], v[3]);
+          ov.z = pack_bf16x2(v[4], v[5]);
+          ov.w = pack_bf16x2(v[6], v[7]);
+          *reinterpret_cast<uint4*>((uint16_t*)p.out + o) = ov;
+        }
+      }
+    }
+  }
+}
+
 // Sum the split-K slabs in slice order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p) {
   const int cq = p.Cout >> 2;
@@ -352,8 +712,16 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
   }
 }
 
+// Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
+struct IgemmTune {
+  int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128
+  int nst;     // 2..4
+  int ksplit;  // >= 1
+};
+static thread_local IgemmTune g_tune = {0, 0, 0};
+
 template <int WM, int WN>
-static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
+static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int ksplit_req) {
   constexpr int TC = 32 * WM, TP = 32 * WN;
   p.tiles_n = ceil_div(p.Cout, TC);
   p.tiles_m = ceil_div(p.M, TP);
@@ -362,18 +730,22 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
     set_error("igemm: grid too large");
     return 1;
   }
-  size_t lds = 2 * (size_t)(TC + TP) * 128;
   const int ksteps = ceil_div(p.Ktot, BK);
   p.m_fast = (p.tiles_m <= 4 && ksteps >= 64) ? 1 : 0;
   // split-K when the tile grid cannot fill 256 CUs and K is deep (weight-streaming FC layers,
   // single-clip convs): slices write f32 slabs to the caller's workspace, a second launch reduces.
   p.ksplit = 1;
   p.ks_per = ksteps;
-  if (batch == 1 && p.ws && nblk < 256 && ksteps >= 8) {
-    long long want = (768 + nblk - 1) / nblk;
-    long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
-    long long ks = want;
-    if (ks > ksteps / 4) ks = ksteps / 4;
+  if (batch == 1 && p.ws) {
+    long long ks = 1;
+    const long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
+    if (ksplit_req > 0) {
+      ks = ksplit_req;
+    } else if (nblk < 256 && ksteps >= 8) {
+      ks = (768 + nblk - 1) / nblk;
+      if (ks > ksteps / 4) ks = ksteps / 4;
+    }
+    if (ks > ksteps) ks = ksteps;
     if (ks > cap_ws) ks = cap_ws;
     if (ks > 1) {
       p.ks_per = ceil_div(ksteps, ks);
@@ -381,7 +753,33 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
       p.partial = (float*)p.ws;
     }
   }
-  hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), dim3((unsigned)nblk, p.ksplit, batch), dim3(256), lds, s, p);
+  static const bool use_v1 = getenv("TRACE_IGEMM_V1") != nullptr;
+  const dim3 grid((unsigned)nblk, p.ksplit, batch);
+  // ring depth: 2 stages keep the most workgroups per CU (they overlap each other's load latency)
+  int nst = nst_req ? nst_req : 2;
+  if (nst < 2) nst = 2;
+  if (nst > 4) nst = 4;
+  const size_t stage = (size_t)(TC + TP) * 128;
+  if (use_v1) {
+    hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), grid, dim3(256), 2 * stage, s, p);
+  } else {
+#define TRACE_IGEMM2(D, S)                                                                               \
+  do {                                                                                                   \
+    static bool attr_done = false; /* > 64 KiB of dynamic LDS must be opted into once per kernel */      \
+    if (!attr_done) {                                                                                    \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_bf16_kernel<WM, WN, D, S>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * stage));           \
+      attr_done = true;                                                                                  \
+    }                                                                                                    \
+    hipLaunchKernelGGL((igemm2_bf16_kernel<WM, WN, D, S>), grid, dim3(256), S * stage, s, p);           \
+  } while (0)
+    if (p.dense) {
+      if (nst == 2) TRACE_IGEMM2(true, 2); else if (nst == 3) TRACE_IGEMM2(true, 3); else TRACE_IGEMM2(true, 4);
+    } else {
+      if (nst == 2) TRACE_IGEMM2(false, 2); else if (nst == 3) TRACE_IGEMM2(false, 3); else TRACE_IGEMM2(false, 4);
+    }
+#undef TRACE_IGEMM2
+  }
   if (p.ksplit > 1) {
     long long n4 = (long long)p.M * (p.Cout >> 2);
     hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
@@ -391,18 +789,38 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
 
 static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
   if (p.M <= 0 || p.Cout <= 0 || batch <= 0) return 0;
-  // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
-  auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
-  if (p.Cout <= 64) return launch_cfg<2, 4>(p, batch, s);        // 64 couts x 128 positions
-  if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) return launch_cfg<4, 2>(p, batch, s);  // weight streaming + split-K
-  if (blocks(128, 128) >= 512) return launch_cfg<4, 4>(p, batch, s);
-  if (blocks(128, 64) >= 384) return launch_cfg<4, 2>(p, batch, s);
-  return launch_cfg<2, 2>(p, batch, s);                           // 64 x 64: small problems
+  p.narrow = (p.Cout % 8 != 0 || p.ldo % 8 != 0) ? 1 : 0;
+  p.dense = (p.kt == 1 && p.kh == 1 && p.kw == 1 && p.st == 1 && p.sh == 1 && p.sw == 1 && p.pt == 0 && p.ph == 0 &&
+             p.pw == 0 && p.Crun == p.Ktot && p.in_n_stride == (long long)p.Ti * p.Hi * p.Wi * p.pix)
+                ? 1 : 0;
+  const IgemmTune t = g_tune;
+  int tile = t.tile;
+  if (!tile) {
+    // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
+    auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
+    if (p.Cout <= 64) tile = 2;                                                   // 64 couts x 128 positions
+    else if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) tile = 3;        // weight streaming + split-K
+    else if (blocks(128, 128) >= 512) tile = 4;
+    else if (blocks(128, 64) >= 384) tile = 3;
+    else tile = 1;                                                                // 64 x 64: small problems
+  }
+  switch (tile) {
+    case 1: return launch_cfg<2, 2>(p, batch, s, t.nst, t.ksplit);
+    case 2: return launch_cfg<2, 4>(p, batch, s, t.nst, t.ksplit);
+    case 3: return launch_cfg<4, 2>(p, batch, s, t.nst, t.ksplit);
+    default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
+  }
 }
 
 }  // namespace trace
 
 using namespace trace;
+
+extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
+  TRACE_REQUIRE(tile >= 0 && tile <= 4 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
+  g_tune = IgemmTune{tile, nst, ksplit};
+  return 0;
+}
 
 extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi, int Wi, int Cin,
                                        const uint16_t* w, const float* bias, int Cout, int kt,
@@ -522,7 +940,7 @@ extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, 
   p.To = 1; p.Ho = 1; p.Wo = M; p.Ti = 1; p.Hi = 1; p.Wi = M;
   p.kt = 1; p.kh = 1; p.kw = 1;
   p.st = 1; p.sh = 1; p.sw = 1; p.dt = 1; p.dh = 1; p.dw = 1;
-  p.in_n_stride = 0;
+  p.in_n_stride = (long long)M * lda;  // single 'clip': n is always 0
   p.pix = lda;
   p.ldw = ldb;
   p.ldo = ldc;

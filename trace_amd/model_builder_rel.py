@@ -33,7 +33,7 @@ from . import ops
 from .config import TraceConfig, vidvrd_config
 from .heads import (cluster_tree3d, fast_rcnn_outputs, init_msra_conv, init_xavier, roi_2mlp_head,
                     xavier_fill)
-from .resnet3d import ResNet3d, i3d_dc5_config
+from .resnet3d import _PACK_EPOCH, ResNet3d, i3d_dc5_config
 
 
 class FrequencyBias(nn.Module):
@@ -71,12 +71,20 @@ class _Upload:
         self.nbytes = (self.nbytes + a.nbytes + 255) // 256 * 256
         return len(self.items) - 1
 
-    def commit(self, dev):
+    def commit(self, dev, into=None):
+        """Copy to the device (stream-ordered, pinned staging) and return the per-array views; `into` is
+        an existing device buffer of the same layout (the resident buffer of a captured step)."""
         host = torch.empty((max(self.nbytes, 256),), dtype=torch.uint8, pin_memory=True)
         hv = host.numpy()
         for off, a in self.items:
             hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
-        d = host.to(dev, non_blocking=True)
+        if into is None:
+            d = host.to(dev, non_blocking=True)
+        else:
+            if into.numel() != host.numel():
+                raise RuntimeError("upload layout changed under a captured step")
+            into.copy_(host, non_blocking=True)
+            d = into
         return [d[off:off + a.nbytes].view(self._DT[a.dtype]).view(a.shape) for off, a in self.items]
 
 
@@ -139,14 +147,21 @@ class Generalized_RCNN(nn.Module):
         # replay the I3D launches from a HIP graph (one graph per clip-batch shape); serving loops with a
         # fixed batch shape switch this on, shape-varying callers leave it off
         self.graph_backbone = False
+        # replay the WHOLE step (backbone + head) from one HIP graph per step signature
+        self.graph_step = False
+        self._step_graphs = {}
+        self._last_step_entry = None
+        self._pk_epoch = 0
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
         self._pk = {}
+        self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._pk = {}
+        self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
         return super().load_state_dict(*a, **k)
 
     def _cached(self, key, make):
@@ -254,7 +269,59 @@ class Generalized_RCNN(nn.Module):
             raise ValueError('You should call this function only on inference. '
                              'Set the network in inference mode by net.eval().')
         with torch.no_grad():
-            return self._forward(all_frames, blob_conv, feat_map, det_rois, im_scale, f_scale, topk, prd_k)
+            dev = all_frames.device
+            prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale)
+            if self.graph_step and ops.IGEMM_TRACE is None:
+                res = self._replay_step(all_frames, blob_conv, feat_map, prep, topk, prd_k)
+            else:
+                dv = prep["upl"].commit(dev)
+                res = self._device_forward(all_frames, self._nhwc(blob_conv), self._nhwc(feat_map), prep, dv, topk,
+                                           prd_k, self.graph_backbone)
+            return self._make_outs(prep, res, topk, prd_k)
+
+    # ------------------------------------------------------------------ whole-step HIP graph
+    def _replay_step(self, all_frames, blob_conv, feat_map, prep, topk, prd_k):
+        """One captured graph per step signature (clip shape, objects / tree regions per clip): every launch
+        of the step - backbone, ROIAligns, GEMMs, attention, tree-GRU, ranking - is replayed with one call.
+        Per step only the packed host arrays (one pinned copy) and, unless the caller already writes
+        into the graph's buffers (`step_buffers`), the clip and the two 2-D maps are copied in.  The
+        returned tensors are the graph's output buffers: they are overwritten by the next replay."""
+        dev = all_frames.device
+        key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
+               feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch)
+        ent = self._step_graphs.get(key)
+        if ent is None:
+            frames_s = all_frames.detach().clone(memory_format=torch.contiguous_format)
+            blob_s, fmap_s = self._nhwc(blob_conv).clone(), self._nhwc(feat_map).clone()
+            dv_buf = torch.empty((max(prep["upl"].nbytes, 256),), dtype=torch.uint8, device=dev)
+            dv = prep["upl"].commit(dev, into=dv_buf)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):            # packs weights, sizes workspaces, warms the allocator
+                self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
+            ent = dict(graph=g, frames=frames_s, blob=blob_s, fmap=fmap_s, dv=dv_buf, res=res)
+            self._step_graphs[key] = ent
+        else:
+            prep["upl"].commit(dev, into=ent["dv"])
+        if all_frames.data_ptr() != ent["frames"].data_ptr():
+            ent["frames"].copy_(all_frames)
+        if blob_conv.data_ptr() != ent["blob"].data_ptr():
+            ent["blob"].copy_(self._nhwc(blob_conv))
+        if feat_map.data_ptr() != ent["fmap"].data_ptr():
+            ent["fmap"].copy_(self._nhwc(feat_map))
+        ent["graph"].replay()
+        self._last_step_entry = ent
+        return ent["res"]
+
+    def step_buffers(self):
+        """(clip, blob_conv, feat_map) input buffers of the most recently replayed step graph: a loader that
+        fills them in place (channels-last bf16 maps) saves the per-step copies."""
+        e = self._last_step_entry
+        return e["frames"], e["blob"], e["fmap"]
 
     @staticmethod
     def _nhwc(x):
@@ -262,23 +329,11 @@ class Generalized_RCNN(nn.Module):
             return x.contiguous()
         return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
-    def _forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale, f_scale, topk, prd_k):
+    def _host_prep(self, det_rois, Tn, im_scale, f_scale):
+        """Host side of a step: roi lists, box trees, pair lists (numpy, as in the reference), packed for
+        one upload.  `sig` identifies every launch shape of the step."""
         cfg = self.cfg
-        dev = all_frames.device
-        B = all_frames.shape[0]
-        ps = self.pool_size
-        D, low = cfg.MLP_HEAD_DIM, cfg.LOW_FEAT_DIM
-        C = cfg.CONV_BODY_DIM
-        ct3 = self.cluster_tree3d
-        # ---- I3D backbone: launched first, the host work below overlaps it (:978-981)
-        i3d = self.Prd_RCNN.forward_ndhwc_graphed if self.graph_backbone else self.Prd_RCNN.forward_ndhwc
-        tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
-        Tn = tmaps.shape[1]
-        tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
-        blob = self._nhwc(blob_conv)
-        fmap = self._nhwc(feat_map)
-
-        # ---- host: roi lists, box trees, pair lists (numpy, as in the reference)
+        B = len(det_rois)
         n_list = [int(r.shape[0]) for r in det_rois]
         off = np.concatenate([[0], np.cumsum(n_list)]).astype(np.int64)
         Ntot = int(off[-1])
@@ -334,8 +389,29 @@ class Generalized_RCNN(nn.Module):
                   reg=upl.add(np.concatenate(reg_rois, 0)),
                   pclip=upl.add(np.repeat(np.arange(B), np.diff(poff)).astype(np.int64)),
                   poff=upl.add(poff[:-1].astype(np.int64)))
-        dv = upl.commit(dev)
-        forest = {k: dv[i] for k, i in zip(forest_keys, forest_ix)}
+        return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
+                    det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
+                    sig=(Tn, tuple(n_list), tuple(m_list)))
+
+    def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone):
+        """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
+        whole of it can be captured into a HIP graph.  Returns flat tensors over all clips."""
+        cfg = self.cfg
+        dev = all_frames.device
+        B = all_frames.shape[0]
+        ps = self.pool_size
+        D, low = cfg.MLP_HEAD_DIM, cfg.LOW_FEAT_DIM
+        C = cfg.CONV_BODY_DIM
+        ct3 = self.cluster_tree3d
+        ix, Ntot, Mtot, poff = prep["ix"], prep["Ntot"], prep["Mtot"], prep["poff"]
+        # ---- I3D backbone (:978-981)
+        i3d = self.Prd_RCNN.forward_ndhwc_graphed if graph_backbone else self.Prd_RCNN.forward_ndhwc
+        tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
+        Tn = tmaps.shape[1]
+        if Tn != prep["Tn"]:
+            raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))
+        tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
+        forest = {k: dv[i] for k, i in zip(prep["forest_keys"], prep["forest_ix"])}
         det_all_d, node_obj_d, node_reg_d = dv[ix["det"]], dv[ix["node_obj"]], dv[ix["node_reg"]]
         X, Y, LCA, union_d = dv[ix["X"]], dv[ix["Y"]], dv[ix["LCA"]], dv[ix["union"]]
 
@@ -427,32 +503,42 @@ class Generalized_RCNN(nn.Module):
             logits = logits + self.freq_bias.rel_index_with_labels(torch.stack((lab[X], lab[Y]), 1))  # :1064,:1075
         prd = torch.sigmoid(logits) if cfg.MULTI_RELATION else F.softmax(logits, dim=1)   # :1083 / :1090
 
-        # ---- per-clip return dicts (:1162-1182); gathers and the ranking run once over all clips
+        # ---- gathers and the ranking run once over all clips (:1162-1182 values)
         sbj_lab_all, obj_lab_all = det_labels[X], det_labels[Y]
         sbj_sc_all, obj_sc_all = det_scores[X], det_scores[Y]
         top = None
         if topk:
             top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
                                              dv[ix["pclip"]], poff, dv[ix["poff"]], topk, prd_k)
+        self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
+                           q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
+                           logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)
+        return dict(det_labels=det_labels, det_scores=det_scores, sbj_labels=sbj_lab_all, obj_labels=obj_lab_all,
+                    sbj_scores=sbj_sc_all, obj_scores=obj_sc_all, msp_det_scores=obj_score, prd_scores=prd, top=top)
+
+    @staticmethod
+    def _make_outs(prep, res, topk, prd_k):
+        """Per-clip return dicts (:1162-1182): views into the step's flat tensors + the host-side roi lists."""
+        off, poff, det_all, pairs = prep["off"], prep["poff"], prep["det_all"], prep["pairs"]
+        top = res["top"]
+        nprd = res["prd_scores"].shape[1]
         outs = []
-        for b in range(B):
+        for b in range(prep["B"]):
             s, o = pairs[b][0], pairs[b][1]
             rois_b = det_all[off[b]:off[b + 1]].copy()
             rois_b[:, 0] = 0
             sl = slice(int(poff[b]), int(poff[b + 1]))
             ol = slice(int(off[b]), int(off[b + 1]))
             d = dict(sbj_rois=rois_b[s], obj_rois=rois_b[o], det_rois=rois_b, sbj_inds=s, obj_inds=o,
-                     det_labels=det_labels[ol], det_scores=det_scores[ol],
-                     sbj_labels=sbj_lab_all[sl], obj_labels=obj_lab_all[sl],
-                     sbj_scores=sbj_sc_all[sl], obj_scores=obj_sc_all[sl],
-                     msp_det_scores=obj_score[ol], prd_scores=prd[sl], prd_ttl_scores=prd[sl])
+                     det_labels=res["det_labels"][ol], det_scores=res["det_scores"][ol],
+                     sbj_labels=res["sbj_labels"][sl], obj_labels=res["obj_labels"][sl],
+                     sbj_scores=res["sbj_scores"][sl], obj_scores=res["obj_scores"][sl],
+                     msp_det_scores=res["msp_det_scores"][ol], prd_scores=res["prd_scores"][sl],
+                     prd_ttl_scores=res["prd_scores"][sl])
             if top is not None:
-                k = min(topk, (int(poff[b + 1]) - int(poff[b])) * min(prd_k, prd.shape[1]))
+                k = min(topk, (int(poff[b + 1]) - int(poff[b])) * min(prd_k, nprd))
                 d.update({name: v[b, :k] for name, v in top.items()})
             outs.append(d)
-        self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
-                           q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
-                           logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)
         return outs
 
     @staticmethod

@@ -335,6 +335,16 @@ class ResNet3d(nn.Module):
                     x = ops.maxpool3d(x, (2, 1, 1), (2, 1, 1))
         return x
 
+    def out_frames(self, T):
+        """Temporal length of the output for a T-frame clip (stem conv, pool1, pool2; the residual stages
+        keep the temporal resolution unless temporal_strides say otherwise)."""
+        kt = self.conv1_kernel[0]
+        t = (T + 2 * ((kt - 1) // 2) - kt) // self.conv1_stride_t + 1
+        t = (t - 1) // self.pool1_stride_t + 1
+        if self.with_pool2:
+            t = (t - 2) // 2 + 1
+        return t
+
     def forward_ndhwc_graphed(self, x, in_ntchw=False):
         """`forward_ndhwc` replayed from a HIP graph: the backbone is ~140 fixed-shape launches per
         batch, so it is captured once per (shape, layout) and re-launched with one call.  The graph
