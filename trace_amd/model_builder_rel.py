@@ -152,6 +152,8 @@ class Generalized_RCNN(nn.Module):
         self._step_graphs = {}
         self._last_step_entry = None
         self._pk_epoch = 0
+        self._side_streams = {}
+        self.side_stream = False
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -404,6 +406,56 @@ class Generalized_RCNN(nn.Module):
         C = cfg.CONV_BODY_DIM
         ct3 = self.cluster_tree3d
         ix, Ntot, Mtot, poff = prep["ix"], prep["Ntot"], prep["Mtot"], prep["poff"]
+        forest = {k: dv[i] for k, i in zip(prep["forest_keys"], prep["forest_ix"])}
+        det_all_d, node_obj_d, node_reg_d = dv[ix["det"]], dv[ix["node_obj"]], dv[ix["node_reg"]]
+        X, Y, LCA, union_d = dv[ix["X"]], dv[ix["Y"]], dv[ix["LCA"]], dv[ix["union"]]
+        E = cfg.OBJ_EMBED_DIM
+
+        # ---- everything that does not read the temporal maps.  With `side_stream` it is forked onto a
+        # second stream next to the backbone and joined before the temporal branches; measured on MI355X
+        # this LOSES 10 % inside the captured step graph (1604 -> 1457 clips/s: the branch costs more in
+        # graph-node synchronisation than the overlap returns), so it stays off by default.
+        main = torch.cuda.current_stream(dev)
+        side = main
+        if self.side_stream:
+            side = self._side_streams.get(dev.index)
+            if side is None:
+                side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+        with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
+            # detection heads (:742-743, :938-952)
+            pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
+            pooled = pooled.view(Ntot, ps * ps * C)
+            h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True)
+            ori = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True)
+            det_s = self._gemm(h1[:, D:2 * D], "s_fc2", [self.S_Head.fc2], out_f32=True)   # NO_FC7_RELU
+            det_o = self._gemm(h1[:, 2 * D:], "o_fc2", [self.O_Head.fc2], out_f32=True)
+            if not cfg.NO_FC7_RELU:
+                det_s, det_o = F.relu(det_s), F.relu(det_o)
+            cls = F.softmax(self._gemm(F.relu(ori), "cls", [self.Box_Outs.cls_score], out_f32=True), dim=1)
+            det_scores, det_labels = cls[:, 1:].max(dim=1)                           # :903-904
+            det_labels = det_labels + 1
+            emb = self._gemm(cls, "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], out_f32=True, leaky=True)
+            det_feat = ori + self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True)  # :945-946
+            # regions (:222-245)
+            reg_map = ops.roi_align_nhwc(fmap, dv[ix["reg"]], cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
+            r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
+            reg_feat = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True)
+            # K / V maps of the pair attention (:287-289, :1545-1546)
+            fm2 = fmap.view(-1, fmap.shape[-1])
+            kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+            vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+            # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069)
+            low_s = self._gemm(emb[:, E:2 * E], "sem_s_e", [self.sem_s_e[1]], out_f32=True)
+            low_o = self._gemm(emb[:, 2 * E:3 * E], "sem_o_e", [self.sem_o_e[1]], out_f32=True)
+            part_s = self._gemm(det_s, "sem_s", [self.sem_s[0]], out_f32=True)
+            part_o = self._gemm(det_o, "sem_o", [self.sem_o[0]], out_f32=True)
+            so_bias = low_s[X] + low_o[Y]
+            so_part = part_s[X] + part_o[Y]
+            sbj_lab_all, obj_lab_all = det_labels[X], det_labels[Y]
+            sbj_sc_all, obj_sc_all = det_scores[X], det_scores[Y]
+            if cfg.USE_FREQ_BIAS:
+                so_part = so_part + self.freq_bias.rel_index_with_labels(torch.stack((sbj_lab_all - 1, obj_lab_all - 1), 1))  # :1064,:1075
         # ---- I3D backbone (:978-981)
         i3d = self.Prd_RCNN.forward_ndhwc_graphed if graph_backbone else self.Prd_RCNN.forward_ndhwc
         tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
@@ -411,25 +463,8 @@ class Generalized_RCNN(nn.Module):
         if Tn != prep["Tn"]:
             raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))
         tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
-        forest = {k: dv[i] for k, i in zip(prep["forest_keys"], prep["forest_ix"])}
-        det_all_d, node_obj_d, node_reg_d = dv[ix["det"]], dv[ix["node_obj"]], dv[ix["node_reg"]]
-        X, Y, LCA, union_d = dv[ix["X"]], dv[ix["Y"]], dv[ix["LCA"]], dv[ix["union"]]
-
-        # ---- detection heads on the key frame (:742-743, :938-952)
-        pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
-        pooled = pooled.view(Ntot, ps * ps * C)
-        h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True)
-        ori = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True)
-        det_s = self._gemm(h1[:, D:2 * D], "s_fc2", [self.S_Head.fc2], out_f32=True)   # NO_FC7_RELU
-        det_o = self._gemm(h1[:, 2 * D:], "o_fc2", [self.O_Head.fc2], out_f32=True)
-        if not cfg.NO_FC7_RELU:
-            det_s, det_o = F.relu(det_s), F.relu(det_o)
-        cls = F.softmax(self._gemm(F.relu(ori), "cls", [self.Box_Outs.cls_score], out_f32=True), dim=1)
-        det_scores, det_labels = cls[:, 1:].max(dim=1)                           # :903-904
-        det_labels = det_labels + 1
-        emb = self._gemm(cls, "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], out_f32=True, leaky=True)
-        E = cfg.OBJ_EMBED_DIM
-        det_feat = ori + self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True)  # :945-946
+        if self.side_stream:
+            main.wait_stream(side)
 
         # ---- cluster_tree3d: temporal object features (:158-201)
         def temporal_branch(rois_d, cur_feat, fc, q_s_l, q_o_l, val, tag):
@@ -445,11 +480,7 @@ class Generalized_RCNN(nn.Module):
 
         obj_agg = temporal_branch(dv[ix["t_obj"]], det_feat, ct3.temporal_obj_fc, ct3.temporal_obj_atten_q_s,
                                   ct3.temporal_obj_atten_q_o, ct3.temporal_obj_feat_val, "tobj")
-        # ---- regions (:222-305)
-        reg_rois_d = dv[ix["reg"]]
-        reg_map = ops.roi_align_nhwc(fmap, reg_rois_d, cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
-        r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
-        reg_feat = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True)
+        # ---- temporal region features (:268-305)
         reg_agg = temporal_branch(dv[ix["t_reg"]], reg_feat, ct3.temporal_r_fc, ct3.temporal_r_atten_q_s,
                                   ct3.temporal_r_atten_q_o, ct3.temporal_r_feat_val, "treg")
         # ---- tree message passing (:307-330)
@@ -475,9 +506,6 @@ class Generalized_RCNN(nn.Module):
         lo = F.leaky_relu(obj_feature, 0.1)
         q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
         q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
-        fm2 = fmap.view(-1, fmap.shape[-1])
-        kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
-        vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
         s_map, o_map, v_map = ops.pair_attention(kmap, vmap, union_d, X, Y, q_s.contiguous(), q_o.contiguous(),
                                                  cfg.REL_SPATIAL_SCALE, ps)
         P = union_d.shape[0]
@@ -489,23 +517,14 @@ class Generalized_RCNN(nn.Module):
         sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
         spatio_infer = self._gemm(sp.view(P, ps * ps * low), "sp_fc", [self.spatio_infer_fc[0]], (low, ps * ps), leaky=True)  # :1042 (+ leaky of :329)
         logit_spa = self._gemm(spatio_infer, "rel_spa", [self.relation_infer_spa[2]], out_f32=True)
-        # ---- semantic branch (:1643-1668)
-        low_s = self._gemm(emb[:, E:2 * E], "sem_s_e", [self.sem_s_e[1]], out_f32=True)
-        low_o = self._gemm(emb[:, 2 * E:3 * E], "sem_o_e", [self.sem_o_e[1]], out_f32=True)
+        # ---- semantic branch (:1643-1668); the subject / object terms were formed on the side stream
         low_r = self._gemm(pf_reg, "sem_r", [self.sem_r[1]], out_f32=True)
-        sem = F.leaky_relu(low_s[X] + low_r[LCA] + low_o[Y], 0.1)
+        sem = F.leaky_relu(so_bias + low_r[LCA], 0.1)
         logit_sem = self._gemm(sem, "rel_sem", [self.relation_infer_sem[2]], out_f32=True)
-        part_s = self._gemm(det_s, "sem_s", [self.sem_s[0]], out_f32=True)
-        part_o = self._gemm(det_o, "sem_o", [self.sem_o[0]], out_f32=True)
-        logits = logit_spa + logit_sem + part_s[X] + part_o[Y]                   # :1066-1069
-        if cfg.USE_FREQ_BIAS:
-            lab = det_labels - 1
-            logits = logits + self.freq_bias.rel_index_with_labels(torch.stack((lab[X], lab[Y]), 1))  # :1064,:1075
+        logits = logit_spa + logit_sem + so_part                                 # :1066-1069 (+ freq bias :1075)
         prd = torch.sigmoid(logits) if cfg.MULTI_RELATION else F.softmax(logits, dim=1)   # :1083 / :1090
 
         # ---- gathers and the ranking run once over all clips (:1162-1182 values)
-        sbj_lab_all, obj_lab_all = det_labels[X], det_labels[Y]
-        sbj_sc_all, obj_sc_all = det_scores[X], det_scores[Y]
         top = None
         if topk:
             top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,

@@ -27,13 +27,34 @@ WORKSPACE_BYTES = 64 << 20
 _RECORDING = None
 
 
+_WS_SLOT = 0
+
+
+class workspace_slot:
+    """Launches made inside use split-K scratch `slot` of their device: two streams that run GEMMs
+    concurrently (the head's side stream next to the backbone) must not share one scratch buffer."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def __enter__(self):
+        global _WS_SLOT
+        self.prev, _WS_SLOT = _WS_SLOT, self.slot
+        return self
+
+    def __exit__(self, *a):
+        global _WS_SLOT
+        _WS_SLOT = self.prev
+        return False
+
+
 def workspace(device):
-    """Per-device split-K scratch handed to the igemm entry points (the library allocates nothing).
-    One buffer per device: calls that use it must be ordered on one stream."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Per-device (and per slot) split-K scratch handed to the igemm entry points (the library allocates
+    nothing).  Calls that share a buffer must be ordered on one stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _WS_SLOT)
     ws = _WS.get(key)
     if ws is None:
-        ws = torch.empty((WORKSPACE_BYTES,), dtype=torch.uint8, device=torch.device("cuda", key))
+        ws = torch.empty((WORKSPACE_BYTES,), dtype=torch.uint8, device=torch.device("cuda", key[0]))
         _WS[key] = ws
     return ws
 
