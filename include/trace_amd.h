@@ -234,14 +234,16 @@ int trace_temporal_attention(const float* qs, const float* qo, const float* o,
  * get_attention_mask_map): for every pair p, ROIAlign (adaptive grid) of the
  * K-map and V-map (B,H,W,D) bf16 on the union box of (sbj,obj), scores
  * q_s.K / q_o.K over the PH*PW cells, softmax, multiply into V.
- * Outputs s_map, o_map, v_map (P,PH*PW,D) bf16 — never materialising the
- * pooled K-map in HBM. */
+ * Outputs s_map, o_map (rows of so_stride elements: D for two dense (P,PH*PW,D)
+ * tensors, 2*D with o_map = s_map + D for the interleaved (P,PH*PW,2D) operand of
+ * the following A|B 1x1-conv GEMM, which saves the torch.cat copy) and v_map
+ * (P,PH*PW,D) bf16 — never materialising the pooled K-map in HBM. */
 int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap,
                                int B, int H, int W, int D,
                                const float* rel_rois, const int32_t* sbj_inds,
                                const int32_t* obj_inds, int P,
                                const float* q_s, const float* q_o,
-                               float spatial_scale, int pooled,
+                               float spatial_scale, int pooled, int so_stride,
                                uint16_t* s_map, uint16_t* o_map,
                                uint16_t* v_map, trace_stream_t stream);
 

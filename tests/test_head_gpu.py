@@ -74,7 +74,7 @@ def test_head_matches_oracle(setup, B, T, n):
                 ("obj_agg", dbg["obj_agg"][off:off + nb], ref["obj_agg"]),
                 ("obj_feature", dbg["obj_feature"][off:off + nb], ref["obj_feature"]),
                 ("q_s", dbg["q_s"][off:off + nb], ref["q_s"]),
-                ("s_map", dbg["s_map"][poff:poff + P].view(P, 49, 256).permute(0, 2, 1).reshape(P, 256, 7, 7), ref["s_map"]),
+                ("s_map", dbg["s_map"][poff:poff + P].reshape(P, 49, 256).permute(0, 2, 1).reshape(P, 256, 7, 7), ref["s_map"]),
                 ("v_map", dbg["v_map"][poff:poff + P].view(P, 49, 256).permute(0, 2, 1).reshape(P, 256, 7, 7), ref["v_p"]),
                 ("logits", dbg["logits"][poff:poff + P], ref["logits"]),
                 ("obj_score", o["msp_det_scores"], ref["obj_scores"])):

@@ -105,7 +105,7 @@ def test_pair_attention_fused_vs_unfused():
         s, o, rel = np_oracle.relpn_pairs(r)
         rois.append(rel.astype(np.float32)); X.append(s + b * n); Y.append(o + b * n)
     rel = np.concatenate(rois); X = np.concatenate(X); Y = np.concatenate(Y)
-    s_map, o_map, v_map = ops.pair_attention(kmap.to(DEV), vmap.to(DEV), torch.from_numpy(rel).to(DEV),
+    s_map, o_map, v_map, _ = ops.pair_attention(kmap.to(DEV), vmap.to(DEV), torch.from_numpy(rel).to(DEV),
                                              torch.from_numpy(X).to(DEV), torch.from_numpy(Y).to(DEV),
                                              q_s.to(DEV), q_o.to(DEV), 1 / 16., 7)
     kp = torch.from_numpy(c_oracle.roi_align_fwd(kmap.float().permute(0, 3, 1, 2).numpy(), rel, 1 / 16., 7, 7, 0))
@@ -114,7 +114,7 @@ def test_pair_attention_fused_vs_unfused():
     for q, idx, got in ((q_s, X, s_map), (q_o, Y, o_map)):
         score = (q[idx].view(P, D, 1, 1) * kp).sum(1).view(P, -1)
         ref = vp * F.softmax(score, 1).view(P, 1, 7, 7)
-        got = got.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
+        got = got.float().cpu().reshape(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
         assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
     gv = v_map.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
     assert float((gv - vp).abs().max()) <= 1e-2 * float(vp.abs().max())

@@ -85,6 +85,24 @@ def test_roi_align_nhwc_bf16(sr):
     np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("sr", [0, 2])
+def test_roi_align_avg_nhwc_bf16(sr):
+    """ROIAlign fused with the 7x7 mean (box_head3d.py:59-61): the separable pixel-weight kernel against
+    the pinned ROIAlign oracle followed by a mean; includes degenerate, out-of-map and whole-map rois."""
+    from trace_amd import ops
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((3, 64, 14, 14)).astype(np.float32)
+    xb = torch.from_numpy(x).to(DEV).to(torch.bfloat16)
+    xr = xb.float().cpu().numpy()
+    rois = _rois(rng, 40, 3)
+    extra = np.array([[0, 10, 10, 10, 10], [1, -40, -40, 30, 30], [2, 200, 200, 300, 300], [0, 0, 0, 223, 223],
+                      [1, 500, 500, 600, 600], [2, -100, 50, -50, 90]], np.float32)
+    rois = np.concatenate([rois, extra], 0)
+    out = ops.roi_align_avg_nhwc(xb.permute(0, 2, 3, 1).contiguous(), torch.from_numpy(rois).to(DEV), 1 / 16., 7, sr)
+    ref = c_oracle.roi_align_fwd(xr, rois, 1 / 16., 7, 7, sr).mean(axis=(2, 3))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-2, atol=1e-2)
+
+
 def test_roi_align_full_size_constant_property():
     """BASELINE cfg5-sized call (2100 rois x 2048 ch): a constant map pools to the constant."""
     from trace_amd import _C

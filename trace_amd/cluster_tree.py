@@ -24,22 +24,21 @@ def _sqdist(x, y):
 
 
 def _cluster_layer(feat, l, r, cluster_num):
-    """One agglomeration layer over nodes l..r -> list of child lists, one per new node."""
-    ids = np.arange(l, r + 1)
-    X, Y = np.meshgrid(ids, ids, indexing='ij')
-    distance = _sqdist(feat[X], feat[Y]).reshape(len(ids), -1)
+    """One agglomeration layer over nodes l..r -> (centres, rest, owner): `centres[k]` founds new node k,
+    `rest[i]` joins new node `owner[i]`.  Same float32 expressions as the reference, evaluated on
+    broadcast views instead of index meshes (element values and reduction order are identical)."""
+    sub = feat[l:r + 1]
+    distance = _sqdist(sub[:, None, :], sub[None, :, :])
     score = -np.sum(np.exp(-distance), axis=1)          # density score (:601)
-    ids = ids[np.argsort(score)]                         # (:602-603)
-    ids = np.hstack((ids[0::2], ids[1::2]))              # even ranks become centres (:604-606)
+    ids = np.argsort(score) + l                          # (:602-603)
+    ids = np.concatenate((ids[0::2], ids[1::2]))         # even ranks become centres (:604-606)
     centres, rest = ids[:cluster_num], ids[cluster_num:]
-    children = [[c] for c in centres]
     if len(rest):
-        rest_flat, cen_flat = np.meshgrid(rest, centres)
-        d = _sqdist(feat[cen_flat.reshape(-1)], feat[rest_flat.reshape(-1)]).reshape(cluster_num, -1)
+        d = _sqdist(feat[centres][:, None, :], feat[rest][None, :, :])
         owner = np.argmin(d, axis=0)                     # nearest centre (:584)
-        for i, o in enumerate(owner):
-            children[o].append(rest[i])
-    return children
+    else:
+        owner = np.zeros(0, np.int64)
+    return centres, rest, owner
 
 
 def build_tree(leaf_boxes, max_tree_height=7, partition=2):
@@ -47,37 +46,40 @@ def build_tree(leaf_boxes, max_tree_height=7, partition=2):
     n = leaf_boxes.shape[0]
     if n <= 0:
         raise ValueError("a clip needs at least one box")
-    feat = leaf_boxes.copy()
-    parent = [-1] * n
+    # node count is known up front: n leaves + the layer sizes
+    sizes = []
+    c = int(math.ceil(n))
+    for _ in range(max_tree_height):
+        c = int(math.ceil(float(c) / partition))
+        sizes.append(c)
+        if c <= 1:
+            break
+    if c > 1:                                            # force a root (:543-548)
+        sizes.append(1)
+    if len(sizes) + 1 > MAX_LEVELS:
+        raise ValueError("tree deeper than %d levels" % MAX_LEVELS)
+    total = n + sum(sizes)
+    feat = np.empty((total, 4), leaf_boxes.dtype)
+    feat[:n] = leaf_boxes
+    parent = np.full(total, -1, np.int32)
     level_off = [0, n]
-    cluster_num = int(math.ceil(n))
     l, r = 0, n - 1
-
-    def add_layer(k):
-        nonlocal feat, l, r
-        groups = _cluster_layer(feat, l, r, k)
-        new = []
-        for gi, sons in enumerate(groups):
-            node = r + 1 + gi
-            for s in sons:
-                parent[s] = node
-            sf = feat[sons]
-            new.append(np.array([sf[:, 0].min(), sf[:, 1].min(), sf[:, 2].max(), sf[:, 3].max()]))
-        parent.extend([-1] * k)
-        feat = np.vstack((feat, np.stack(new, axis=0)))
+    for k in sizes:
+        centres, rest, owner = _cluster_layer(feat, l, r, k)
+        new_ids = np.arange(r + 1, r + 1 + k)
+        parent[centres] = new_ids
+        nb = feat[centres].copy()                        # hull of each group (:617-628): min / max are exact
+        if len(rest):
+            parent[rest] = new_ids[owner]
+            rb = feat[rest]
+            np.minimum.at(nb[:, 0], owner, rb[:, 0])
+            np.minimum.at(nb[:, 1], owner, rb[:, 1])
+            np.maximum.at(nb[:, 2], owner, rb[:, 2])
+            np.maximum.at(nb[:, 3], owner, rb[:, 3])
+        feat[r + 1:r + 1 + k] = nb
         l, r = r + 1, r + k
         level_off.append(r + 1)
-
-    for _ in range(max_tree_height):
-        cluster_num = int(math.ceil(float(cluster_num) / partition))
-        add_layer(cluster_num)
-        if cluster_num <= 1:
-            break
-    if cluster_num > 1:                                  # force a root (:543-548)
-        add_layer(1)
-    if len(level_off) - 1 > MAX_LEVELS:
-        raise ValueError("tree deeper than %d levels" % MAX_LEVELS)
-    return dict(parent=np.asarray(parent, np.int32), level_off=level_off, boxes=feat, n_leaf=n)
+    return dict(parent=parent, level_off=level_off, boxes=feat, n_leaf=n)
 
 
 def ancestors(tree):

@@ -58,7 +58,7 @@ constexpr int PA_MAX_CELLS = 64;
 __global__ __launch_bounds__(256) void pair_attention_kernel(
     const uint16_t* __restrict__ kmap, const uint16_t* __restrict__ vmap, int B, int H, int W, int D,
     const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
-    const float* __restrict__ q_s, const float* __restrict__ q_o, float scale, int PS,
+    const float* __restrict__ q_s, const float* __restrict__ q_o, float scale, int PS, int so_stride,
     uint16_t* __restrict__ s_map, uint16_t* __restrict__ o_map, uint16_t* __restrict__ v_map) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sc_s = (float*)smem;              // [PA_MAX_CELLS]
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256) void pair_attention_kernel(
       po[j] = pack_bf16x2(lo * wo, hi * wo);
     }
     const long long o = obase + (long long)cell * D + c8 * 8;
-    *reinterpret_cast<uint4*>(s_map + o) = os;
-    *reinterpret_cast<uint4*>(o_map + o) = oo;
+    const long long oso = ((long long)p * cells + cell) * so_stride + c8 * 8;
+    *reinterpret_cast<uint4*>(s_map + oso) = os;
+    *reinterpret_cast<uint4*>(o_map + oso) = oo;
     *reinterpret_cast<uint4*>(v_map + o) = pk;
   }
 }
@@ -378,8 +379,9 @@ extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* 
                                           int W, int D, const float* rel_rois,
                                           const int32_t* sbj_inds, const int32_t* obj_inds, int P,
                                           const float* q_s, const float* q_o, float spatial_scale,
-                                          int pooled, uint16_t* s_map, uint16_t* o_map,
-                                          uint16_t* v_map, trace_stream_t stream) {
+                                          int pooled, int so_stride, uint16_t* s_map,
+                                          uint16_t* o_map, uint16_t* v_map, trace_stream_t stream) {
+  TRACE_REQUIRE(so_stride >= D && so_stride % 8 == 0, "pair_attention: so_stride=%d must be >= D and a multiple of 8", so_stride);
   TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_attention: bad shape");
   TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_attention: D=%d must be 64/128/256/512", D);
   TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_attention: pooled=%d too large", pooled);
@@ -388,7 +390,7 @@ extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* 
                 "pair_attention: null pointer");
   size_t lds = 2 * PA_MAX_CELLS * sizeof(float) + (size_t)pooled * pooled * D * 2;
   hipLaunchKernelGGL(pair_attention_kernel, dim3(P), dim3(256), lds, (hipStream_t)stream, kmap, vmap, B,
-                     H, W, D, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled, s_map,
+                     H, W, D, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled, so_stride, s_map,
                      o_map, v_map);
   return check_launch("pair_attention_fused");
 }

@@ -268,45 +268,100 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc_bf16_kernel(
 // ROIAlign + AdaptiveAvgPool2d((1,1)) fused (Tail_Layer_3D.map2vec with I3D_DC5,
 // lib/i3d/box_head3d.py:59-61): out (K,C) bf16 = mean over the PH*PW bins of the
 // ROIAlign output, without writing the (K,PH,PW,C) tensor.  One workgroup per roi.
+//
+// The mean over all bins of all bilinear samples is a weighted sum of map pixels, and because the
+// sample grid is a Cartesian product (every y sample meets every x sample, and a sample is dropped
+// iff its y OR its x is out of range) the pixel weight factorises: W[py][px] = Wy[py] * Wx[px].
+// Wy / Wx are built once per roi in LDS (a few dozen 1-D samples each, fixed summation order, no
+// atomics), then every lane accumulates its 8 channels over the roi's pixel box: (roi_h+2)*(roi_w+2)
+// 16-byte loads instead of 4*PH*PW*grid_h*grid_w.
 // ---------------------------------------------------------------------------
+constexpr int RA_MAX_DIM = 1024;  // map height / width limit of the separable kernel
+
+struct Lin1 {
+  int lo, hi;
+  float wl, wh;
+  bool valid;
+};
+// 1-D half of bilinear_interpolate (ROIAlign_cuda.cu:22-57): the y rules and the x rules are identical
+__device__ __forceinline__ Lin1 lin_setup(float v, int n) {
+  Lin1 r;
+  r.valid = !(v < -1.0f || v > (float)n);
+  if (v <= 0.f) v = 0.f;
+  r.lo = (int)v;
+  if (r.lo >= n - 1) {
+    r.hi = r.lo = n - 1;
+    v = (float)r.lo;
+  } else {
+    r.hi = r.lo + 1;
+  }
+  r.wh = v - (float)r.lo;
+  r.wl = 1.0f - r.wh;
+  return r;
+}
+
 __global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(
     const uint16_t* __restrict__ in, int B, int H, int W, int C, const float* __restrict__ rois,
     float scale, int PH, int PW, int sr, uint16_t* __restrict__ out) {
+  __shared__ float wy[RA_MAX_DIM];
+  __shared__ float wx[RA_MAX_DIM];
+  __shared__ int box[4];
   const int n = blockIdx.x;
   RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
   const uint16_t* img = in + (long long)g.batch * H * W * C;
+  // pixel p of an axis collects, over that axis' samples, wl where lo == p and wh where hi == p
+  for (int p = threadIdx.x; p < H + W; p += blockDim.x) {
+    const bool is_y = p < H;
+    const int q = is_y ? p : p - H;
+    const int bins = is_y ? PH : PW, grid = is_y ? g.grid_h : g.grid_w, dim = is_y ? H : W;
+    const float start = is_y ? g.start_h : g.start_w, bsz = is_y ? g.bin_h : g.bin_w;
+    float acc = 0.f;
+    for (int b = 0; b < bins; ++b)
+      for (int i = 0; i < grid; ++i) {
+        const Lin1 l = lin_setup(sample_coord(start, b, bsz, i, grid), dim);
+        if (!l.valid) continue;
+        if (l.lo == q) acc += l.wl;
+        if (l.hi == q) acc += l.wh;
+      }
+    (is_y ? wy : wx)[q] = acc;
+  }
+  if (threadIdx.x < 4) {
+    // pixel range touched by the first / last sample of each axis (samples are monotonic)
+    const bool is_y = threadIdx.x < 2;
+    const int bins = is_y ? PH : PW, grid = is_y ? g.grid_h : g.grid_w, dim = is_y ? H : W;
+    const float start = is_y ? g.start_h : g.start_w, bsz = is_y ? g.bin_h : g.bin_w;
+    const bool first = (threadIdx.x & 1) == 0;
+    const Lin1 l = lin_setup(first ? sample_coord(start, 0, bsz, 0, grid) : sample_coord(start, bins - 1, bsz, grid - 1, grid), dim);
+    box[threadIdx.x] = first ? l.lo : l.hi;
+  }
+  __syncthreads();
+  const int y0 = box[0], y1 = box[1], x0 = box[2], x1 = box[3];
   const float norm = 1.0f / (g.count * (float)(PH * PW));
   for (int c0 = threadIdx.x * 8; c0 < C; c0 += blockDim.x * 8) {
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int ph = 0; ph < PH; ++ph)
-      for (int iy = 0; iy < g.grid_h; ++iy) {
-        float y = sample_coord(g.start_h, ph, g.bin_h, iy, g.grid_h);
-        for (int pw = 0; pw < PW; ++pw)
-          for (int ix = 0; ix < g.grid_w; ++ix) {
-            float x = sample_coord(g.start_w, pw, g.bin_w, ix, g.grid_w);
-            Bilin b = bilin_setup(y, x, H, W);
-            if (!b.valid) continue;
-            uint4 v1 = *reinterpret_cast<const uint4*>(img + (long long)b.p1 * C + c0);
-            uint4 v2 = *reinterpret_cast<const uint4*>(img + (long long)b.p2 * C + c0);
-            uint4 v3 = *reinterpret_cast<const uint4*>(img + (long long)b.p3 * C + c0);
-            uint4 v4 = *reinterpret_cast<const uint4*>(img + (long long)b.p4 * C + c0);
-            const uint32_t* a1 = &v1.x;
-            const uint32_t* a2 = &v2.x;
-            const uint32_t* a3 = &v3.x;
-            const uint32_t* a4 = &v4.x;
+    for (int py = y0; py <= y1; ++py) {
+      const float wyv = wy[py];
+      if (wyv == 0.f) continue;
+      const uint16_t* row = img + ((long long)py * W) * C + c0;
+      float racc[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              acc[2 * j] += b.w1 * __uint_as_float(a1[j] << 16) + b.w2 * __uint_as_float(a2[j] << 16) +
-                            b.w3 * __uint_as_float(a3[j] << 16) + b.w4 * __uint_as_float(a4[j] << 16);
-              acc[2 * j + 1] += b.w1 * __uint_as_float(a1[j] & 0xffff0000u) +
-                                b.w2 * __uint_as_float(a2[j] & 0xffff0000u) +
-                                b.w3 * __uint_as_float(a3[j] & 0xffff0000u) +
-                                b.w4 * __uint_as_float(a4[j] & 0xffff0000u);
-            }
-          }
+      for (int j = 0; j < 8; ++j) racc[j] = 0.f;
+#pragma unroll 4
+      for (int px = x0; px <= x1; ++px) {
+        const float w = wx[px];
+        const uint4 v = *reinterpret_cast<const uint4*>(row + (long long)px * C);
+        const uint32_t* a = &v.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          racc[2 * j] += w * __uint_as_float(a[j] << 16);
+          racc[2 * j + 1] += w * __uint_as_float(a[j] & 0xffff0000u);
+        }
       }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wyv * racc[j];
+    }
     uint4 o;
     o.x = pack_bf16x2(acc[0] * norm, acc[1] * norm);
     o.y = pack_bf16x2(acc[2] * norm, acc[3] * norm);
@@ -420,6 +475,7 @@ extern "C" int trace_roi_align_avg_nhwc_bf16(const uint16_t* input, int B, int H
   TRACE_REQUIRE(C % 8 == 0, "roi_align_avg_nhwc: C=%d must be a multiple of 8", C);
   if (K == 0 || C == 0) return 0;
   TRACE_REQUIRE(input && rois && out, "roi_align_avg_nhwc: null pointer");
+  TRACE_REQUIRE(H <= RA_MAX_DIM && W <= RA_MAX_DIM, "roi_align_avg_nhwc: map %dx%d exceeds %d", H, W, RA_MAX_DIM);
   int threads = C / 8 >= 256 ? 256 : ((C / 8 + 63) / 64) * 64;
   hipLaunchKernelGGL(roi_align_avg_nhwc_bf16_kernel, dim3(K), dim3(threads), 0, (hipStream_t)stream,
                      input, B, H, W, C, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, out);

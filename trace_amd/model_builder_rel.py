@@ -355,13 +355,10 @@ class Generalized_RCNN(nn.Module):
             m = tree["parent"].shape[0] - n
             m_list.append(m)
             t_obj.append(self._temporal_roi_list(boxes, Tn, b * Tn))
-            hull = ct.temporal_hulls(tree, np.repeat(boxes[:, None, :], Tn, axis=1))     # (m,T,4)
-            flat = hull.reshape(-1, 4)                                                   # object-major list
-            jj, tt = np.meshgrid(np.arange(m), np.arange(Tn), indexing="ij")
-            rr = np.empty((m, Tn, 5), np.float32)
-            rr[:, :, 0] = b * Tn + tt
-            rr[:, :, 1:] = flat[tt * m + jj]                                             # same quirk as objects
-            t_reg.append(rr.reshape(-1, 5))
+            # tracklets are static tubes (model_builder_rel.py:1441-1444), so the per-frame hull of a region
+            # (cluster_tree3d.py:368-391: min / max over its sons, exact) is the region's tree box on every
+            # frame; the list keeps the reference's object-major-vs-frame-major pairing (same quirk as objects)
+            t_reg.append(self._temporal_roi_list(tree["boxes"][n:].astype(np.float32), Tn, b * Tn))
             reg_rois.append(np.concatenate([np.full((m, 1), b, np.float32), tree["boxes"][n:].astype(np.float32)], 1))
             if n > 1:
                 s = np.repeat(np.arange(n), n - 1)
@@ -506,10 +503,10 @@ class Generalized_RCNN(nn.Module):
         lo = F.leaky_relu(obj_feature, 0.1)
         q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
         q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
-        s_map, o_map, v_map = ops.pair_attention(kmap, vmap, union_d, X, Y, q_s.contiguous(), q_o.contiguous(),
-                                                 cfg.REL_SPATIAL_SCALE, ps)
+        s_map, o_map, v_map, so = ops.pair_attention(kmap, vmap, union_d, X, Y, q_s.contiguous(), q_o.contiguous(),
+                                                     cfg.REL_SPATIAL_SCALE, ps)
         P = union_d.shape[0]
-        so = torch.cat([s_map, o_map], 2).view(P * ps * ps, 2 * low)
+        so = so.view(P * ps * ps, 2 * low)                                       # [s_map | o_map], written in place
         wab, bab, _ = self._cached("inferAB", lambda: (
             torch.cat([self.spatio_inferA[0].weight.detach().float().view(low, low),
                        self.spatio_inferB[0].weight.detach().float().view(low, low)], 1).to(torch.bfloat16).contiguous(),

@@ -386,7 +386,8 @@ def temporal_attention(qs, qo, o, inv_sqrt_d):
 
 
 def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled=7):
-    """kmap, vmap (B,H,W,D) bf16; returns s_map, o_map, v_map (P, pooled*pooled, D) bf16."""
+    """kmap, vmap (B,H,W,D) bf16; returns s_map, o_map (views of one (P, pooled*pooled, 2D) buffer: the
+    concatenated operand of the A|B 1x1-conv GEMM) and v_map (P, pooled*pooled, D) bf16."""
     kmap, vmap = _bf16(kmap, "kmap"), _bf16(vmap, "vmap")
     rel_rois, q_s, q_o = _f32(rel_rois), _f32(q_s), _f32(q_o)
     L.require_gpu(sbj_inds, obj_inds)
@@ -394,14 +395,16 @@ def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_s
     obj_inds = obj_inds.to(torch.int32).contiguous()
     B, H, W, D = kmap.shape
     P = rel_rois.shape[0]
-    outs = [torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=kmap.device) for _ in range(3)]
+    so = torch.empty((P, pooled * pooled, 2 * D), dtype=torch.bfloat16, device=kmap.device)
+    v = torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=kmap.device)
+    s_map, o_map = so[:, :, :D], so[:, :, D:]
     with torch.cuda.device(kmap.device):
         L.check(L.lib().trace_pair_attention_fused(L.ptr(kmap), L.ptr(vmap), B, H, W, D, L.ptr(rel_rois),
                                                    L.ptr(sbj_inds), L.ptr(obj_inds), P, L.ptr(q_s), L.ptr(q_o),
-                                                   float(spatial_scale), pooled, L.ptr(outs[0]),
-                                                   L.ptr(outs[1]), L.ptr(outs[2]), L.stream()),
+                                                   float(spatial_scale), pooled, 2 * D, L.ptr(s_map),
+                                                   L.ptr(o_map), L.ptr(v), L.stream()),
                 "pair_attention")
-    return outs
+    return s_map, o_map, v, so
 
 
 def tree_gru(x, F, Hd, n_groups, forest, weights):
