@@ -260,7 +260,10 @@ int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap,
  *   parent (n_nodes) global id or -1; children of node v are
  *   child_idx[child_off[v] .. child_off[v+1])
  *   h, hd (n_nodes, n_groups*Hd) f32 outputs (bottom-up / top-down states).
- * Weight matrices are passed TRANSPOSED, i.e. (in_features, Hd) row-major. */
+ * Weight matrices are passed TRANSPOSED, i.e. (in_features, Hd) row-major.
+ * When max_tree_nodes bounds every tree and one tree's state plus one direction's
+ * matrices fit in LDS, the whole pass runs out of LDS (a tree larger than the bound
+ * gets NaN outputs instead of an LDS overrun). */
 #define TRACE_TREE_MAX_LEVELS 12
 #define TRACE_TREE_MAX_GROUPS 8
 typedef struct trace_tree_gru_weights {
@@ -276,6 +279,7 @@ int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups,
                    const int32_t* parent, const int32_t* child_off,
                    const int32_t* child_idx,
                    const trace_tree_gru_weights* weights /* host, n_groups */,
+                   int max_tree_nodes /* upper bound of nodes in one tree; 0 = unknown */,
                    float* h, float* hd,
                    float* workspace /* n_nodes*n_groups*Hd f32 */,
                    trace_stream_t stream);

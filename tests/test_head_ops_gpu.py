@@ -21,9 +21,11 @@ def test_temporal_attention():
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("lds_resident", [False, True])
 @pytest.mark.parametrize("n,G,F_,Hd", [(1, 1, 64, 64), (7, 4, 64, 64), (20, 4, 64, 64), (33, 2, 256, 256)])
-def test_tree_gru_vs_dense_reference(n, G, F_, Hd):
-    """tree-GRU on CSR arrays (HIP) vs the reference's dense-adjacency formulation (oracle)."""
+def test_tree_gru_vs_dense_reference(n, G, F_, Hd, lds_resident):
+    """tree-GRU on CSR arrays (HIP; the level-walking kernel and the LDS-resident one selected by a
+    tree-size bound) vs the reference's dense-adjacency formulation (oracle)."""
     from trace_amd import ops, cluster_tree as ct
     from oracle import np_oracle
     from oracle.head_ref import _tree_gru
@@ -58,7 +60,8 @@ def test_tree_gru_vs_dense_reference(n, G, F_, Hd):
             d["br" + sfx] = sd["tm.%d.Ur%s.0.bias" % (gi, sfx)].to(DEV)
         w.append(d)
     x = torch.cat(feats, 0)
-    h, hd = ops.tree_gru(x.to(DEV), F_, Hd, G, forest, w)
+    bound = max(t["parent"].shape[0] for t in trees) if lds_resident else 0
+    h, hd = ops.tree_gru(x.to(DEV), F_, Hd, G, forest, w, max_tree_nodes=bound)
     off = 0
     for b, tree in enumerate(trees):
         nt = tree["parent"].shape[0]

@@ -50,7 +50,7 @@ SIGNATURES = {
     "trace_temporal_attention": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P]),
     "trace_pair_attention_fused": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, c_float, c_int, c_int, P, P, P, P]),
     "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
-                               ctypes.POINTER(TreeGruWeights), P, P, P, P]),
+                               ctypes.POINTER(TreeGruWeights), c_int, P, P, P, P]),
 }
 
 _lib = None

@@ -359,6 +359,159 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Tree-GRU, LDS-resident variant (used when one tree's state and one direction's matrices fit in
+// LDS: the VidVRD head, F = Hd = 64, <= ~70 nodes per tree).  The pass is a chain of ~2*levels
+// dependent steps, so every operand of the chain lives in LDS:
+//   * per direction, the input terms W{z,r,h} x_v of ALL nodes are computed first (no dependence
+//     between nodes), from LDS-staged W and x rows;
+//   * then the three U matrices replace W in the same LDS region and the levels are walked with
+//     h / hd / the gated sums read and written in LDS only; h and hd go to HBM once at the end;
+//   * U_z applied to the sum of the children states equals the sum of U_z h_c (linear), which saves
+//     one matrix-vector product per extra child.
+// dot products: lane j owns output j; column j of a transposed matrix is one LDS bank, the vector
+// element is a broadcast.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float dot_lds(const float* __restrict__ Wt, int Hd, int j,
+                                         const float* __restrict__ v, int n_in) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int i = 0; i < n_in; i += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(v + i);
+    s0 += Wt[(i + 0) * Hd + j] * x.x;
+    s1 += Wt[(i + 1) * Hd + j] * x.y;
+    s2 += Wt[(i + 2) * Hd + j] * x.z;
+    s3 += Wt[(i + 3) * Hd + j] * x.w;
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, int nn_max) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int t = blockIdx.x, g = blockIdx.y;
+  const TreeW& w = p.w[g];
+  const int F = p.F, Hd = p.Hd;
+  const int FH = F > Hd ? F : Hd;
+  float* R = sm;                       // 3 matrices of one kind: [3][FH][Hd]
+  float* xt = R + 3 * FH * Hd;         // input terms of the current direction [3][nn_max][Hd]
+  float* hl = xt + 3 * nn_max * Hd;    // bottom-up state   [nn_max][Hd]
+  float* hdl = hl + nn_max * Hd;       // top-down state    [nn_max][Hd]
+  float* wsl = hdl + nn_max * Hd;      // gated sums [nn_max][Hd]; first holds the x rows [nn_max][F]
+  const long long ldx = (long long)p.G * F, ldh = (long long)p.G * Hd;
+  const int vb = p.tree_off[t];
+  const int nn = p.tree_off[t + 1] - vb;
+  float* hg = p.h + (long long)g * Hd;
+  float* hdg = p.hd + (long long)g * Hd;
+  if (nn > nn_max) {  // caller's bound was wrong: poison this tree's outputs instead of overrunning LDS
+    for (int idx = threadIdx.x; idx < nn * Hd; idx += blockDim.x) {
+      hg[(vb + idx / Hd) * ldh + idx % Hd] = __builtin_nanf("");
+      hdg[(vb + idx / Hd) * ldh + idx % Hd] = __builtin_nanf("");
+    }
+    return;
+  }
+  const int nl = p.n_levels[t];
+  const int32_t* lo = p.level_off + (long long)t * (TRACE_TREE_MAX_LEVELS + 1);
+  const float* xg = p.x + (long long)g * F;
+
+  auto stage3 = [&](const float* a0, const float* a1, const float* a2, int rows) {
+    const float* srcs[3] = {a0, a1, a2};
+    const int n = rows * Hd;
+    for (int k = 0; k < 3; ++k)
+      for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4)
+        *reinterpret_cast<float4*>(R + k * FH * Hd + i) = *reinterpret_cast<const float4*>(srcs[k] + i);
+  };
+  auto input_terms = [&](const float* Wz, const float* Wr, const float* Wh) {
+    __syncthreads();  // everyone is done with R / wsl of the previous phase
+    stage3(Wz, Wr, Wh, F);
+    for (int idx = threadIdx.x * 4; idx < nn * F; idx += blockDim.x * 4) {
+      const int v = idx / F, i = idx - v * F;
+      *reinterpret_cast<float4*>(wsl + v * F + i) = *reinterpret_cast<const float4*>(xg + (vb + v) * ldx + i);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 3 * nn * Hd; idx += blockDim.x) {
+      const int k = idx / (nn * Hd), r = idx - k * nn * Hd;
+      const int v = r / Hd, j = r - v * Hd;
+      xt[(k * nn_max + v) * Hd + j] = dot_lds(R + k * FH * Hd, Hd, j, wsl + v * F, F);
+    }
+    __syncthreads();
+  };
+  const float* Uz = R;
+  const float* Ur = R + FH * Hd;
+  const float* Uh = R + 2 * FH * Hd;
+  const float* xz = xt;
+  const float* xr = xt + nn_max * Hd;
+  const float* xh = xt + 2 * nn_max * Hd;
+
+  // ================= bottom-up (cluster_tree.py:281-316)
+  input_terms(w.Wz, w.Wr, w.Wh);
+  stage3(w.Uz, w.Ur, w.Uh, Hd);
+  {  // leaves (:289-292): no bias on the leaf gates, as the reference
+    const int v0 = lo[0] - vb, cnt = (lo[1] - lo[0]) * Hd;
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float z = sigmoidf_(xz[v * Hd + j]);
+      const float c = tanhf(xh[v * Hd + j]);
+      hl[v * Hd + j] = (1.0f - z) * c;
+    }
+  }
+  __syncthreads();
+  for (int l = 1; l < nl; ++l) {
+    const int v0 = lo[l] - vb, cnt = (lo[l + 1] - lo[l]) * Hd;
+    // phase A: ws = sum_c sigmoid(Wr x + Ur h_c + br) * h_c ; hsum kept in hdl (free until top-down)
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float a = xr[v * Hd + j] + w.br[j];
+      float fa = 0.f, hs = 0.f;
+      for (int ci = p.child_off[vb + v]; ci < p.child_off[vb + v + 1]; ++ci) {
+        const float* hc = hl + (p.child_idx[ci] - vb) * Hd;
+        fa += sigmoidf_(a + dot_lds(Ur, Hd, j, hc, Hd)) * hc[j];
+        hs += hc[j];
+      }
+      wsl[v * Hd + j] = fa;
+      hdl[v * Hd + j] = hs;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float hs = hdl[v * Hd + j];
+      const float z = sigmoidf_(xz[v * Hd + j] + w.bz[j] + dot_lds(Uz, Hd, j, hdl + v * Hd, Hd));
+      const float c = tanhf(xh[v * Hd + j] + dot_lds(Uh, Hd, j, wsl + v * Hd, Hd));
+      hl[v * Hd + j] = z * hs + (1.0f - z) * c;
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < nn * Hd; idx += blockDim.x)
+    hg[(vb + idx / Hd) * ldh + idx % Hd] = hl[idx];
+
+  // ================= top-down (cluster_tree.py:189-200, 318-352)
+  input_terms(w.Wzd, w.Wrd, w.Whd);
+  stage3(w.Uzd, w.Urd, w.Uhd, Hd);
+  {
+    const int v0 = lo[nl - 1] - vb, cnt = (lo[nl] - lo[nl - 1]) * Hd;
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) hdl[v0 * Hd + idx] = hl[v0 * Hd + idx];  // roots copy h
+  }
+  __syncthreads();
+  for (int l = nl - 2; l >= 0; --l) {
+    const int v0 = lo[l] - vb, cnt = (lo[l + 1] - lo[l]) * Hd;
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float* hf = hdl + (p.parent[vb + v] - vb) * Hd;
+      const float r = sigmoidf_(xr[v * Hd + j] + dot_lds(Ur, Hd, j, hf, Hd) + w.brd[j]);
+      wsl[v * Hd + j] = r * hf[j];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
+      const int v = v0 + idx / Hd, j = idx % Hd;
+      const float* hf = hdl + (p.parent[vb + v] - vb) * Hd;
+      const float z = sigmoidf_(xz[v * Hd + j] + dot_lds(Uz, Hd, j, hf, Hd) + w.bzd[j]);
+      const float c = tanhf(xh[v * Hd + j] + dot_lds(Uh, Hd, j, wsl + v * Hd, Hd));
+      hdl[v * Hd + j] = z * hf[j] + (1.0f - z) * c;
+    }
+    __syncthreads();
+  }
+  for (int idx = threadIdx.x; idx < nn * Hd; idx += blockDim.x)
+    hdg[(vb + idx / Hd) * ldh + idx % Hd] = hdl[idx];
+}
+
 }  // namespace trace
 
 using namespace trace;
@@ -399,8 +552,8 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
                               const int32_t* tree_off, const int32_t* level_off,
                               const int32_t* n_levels, const int32_t* parent,
                               const int32_t* child_off, const int32_t* child_idx,
-                              const trace_tree_gru_weights* weights, float* h, float* hd,
-                              float* workspace, trace_stream_t stream) {
+                              const trace_tree_gru_weights* weights, int max_tree_nodes, float* h,
+                              float* hd, float* workspace, trace_stream_t stream) {
   TRACE_REQUIRE(n_nodes >= 0 && F > 0 && Hd > 0 && n_groups > 0 && n_trees >= 0, "tree_gru: bad shape");
   TRACE_REQUIRE(n_groups <= TRACE_TREE_MAX_GROUPS, "tree_gru: more than %d groups", TRACE_TREE_MAX_GROUPS);
   if (n_trees == 0 || n_nodes == 0) return 0;
@@ -433,6 +586,23 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
   TRACE_REQUIRE(F % 4 == 0 && Hd % 4 == 0, "tree_gru: F and Hd must be multiples of 4");
   TRACE_REQUIRE((((uintptr_t)x | (uintptr_t)h | (uintptr_t)hd | (uintptr_t)workspace) & 15) == 0,
                 "tree_gru: x/h/hd/workspace must be 16-byte aligned");
+  // LDS-resident pass when the caller bounds the tree size and one direction fits (see the kernel)
+  if (max_tree_nodes > 0) {
+    const int FH = F > Hd ? F : Hd;
+    const size_t need = ((size_t)3 * FH * Hd + (size_t)max_tree_nodes * (6 * Hd + (F > Hd ? F - Hd : 0))) * sizeof(float);  // xt(3) + h + hd + ws|x
+    if (need <= 156 * 1024) {
+      static bool attr2 = false;
+      if (!attr2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr2 = true;
+      }
+      hipLaunchKernelGGL(tree_gru_lds_kernel, dim3(n_trees, n_groups), dim3(256), need, (hipStream_t)stream, p,
+                         max_tree_nodes);
+      return check_launch("tree_gru");
+    }
+  }
   const size_t lds = (size_t)(3 * F * Hd + 3 * Hd * Hd) * sizeof(float);
   if (lds <= 128 * 1024) {
     static bool attr_set = false;  // raise the dynamic-LDS limit once (idempotent)

@@ -390,7 +390,8 @@ class Generalized_RCNN(nn.Module):
                   poff=upl.add(poff[:-1].astype(np.int64)))
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list)))
+                    sig=(Tn, tuple(n_list), tuple(m_list)),
+                    max_tree_nodes=max(n + m for n, m in zip(n_list, m_list)))
 
     def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone):
         """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
@@ -489,7 +490,7 @@ class Generalized_RCNN(nn.Module):
         x_nodes = torch.empty((Ntot + Mtot, fc), dtype=torch.float32, device=dev)
         x_nodes[node_obj_d] = o2c
         x_nodes[node_reg_d] = r2c
-        h, hd = ops.tree_gru(x_nodes, gw, gw, G, forest, self._tree_weights())
+        h, hd = ops.tree_gru(x_nodes, gw, gw, G, forest, self._tree_weights(), max_tree_nodes=prep["max_tree_nodes"])
         hcat = torch.cat([h.view(-1, G, gw), hd.view(-1, G, gw)], 2).to(torch.bfloat16)   # (nodes, G, 2*gw)
         agg = torch.empty((Ntot + Mtot, fc), dtype=torch.bfloat16, device=dev)
         for g, (w12, b12) in enumerate(self._ffn12_w()):

@@ -407,10 +407,11 @@ def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_s
     return s_map, o_map, v, so
 
 
-def tree_gru(x, F, Hd, n_groups, forest, weights):
+def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
     """x (n_nodes, n_groups*F) f32; forest = dict(tree_off, level_off, n_levels, parent, child_off,
     child_idx) of int32 device tensors; weights = list (per group) of dicts holding the 16 TRANSPOSED
-    f32 device tensors named as in trace_tree_gru_weights.  Returns h, hd (n_nodes, n_groups*Hd)."""
+    f32 device tensors named as in trace_tree_gru_weights.  max_tree_nodes: host-known upper bound of the
+    nodes of one tree (enables the LDS-resident kernel).  Returns h, hd (n_nodes, n_groups*Hd)."""
     x = _f32(x)
     n_nodes = x.shape[0]
     dev = x.device
@@ -429,6 +430,6 @@ def tree_gru(x, F, Hd, n_groups, forest, weights):
         L.check(L.lib().trace_tree_gru(L.ptr(x), n_nodes, F, Hd, n_groups, n_trees, L.ptr(forest["tree_off"]),
                                        L.ptr(forest["level_off"]), L.ptr(forest["n_levels"]),
                                        L.ptr(forest["parent"]), L.ptr(forest["child_off"]),
-                                       L.ptr(forest["child_idx"]), arr, L.ptr(h), L.ptr(hd), L.ptr(ws),
+                                       L.ptr(forest["child_idx"]), arr, int(max_tree_nodes), L.ptr(h), L.ptr(hd), L.ptr(ws),
                                        L.stream()), "tree_gru")
     return h, hd
