@@ -372,10 +372,15 @@ __global__ __launch_bounds__(256) void tree_gru_kernel(const TreeParams p) {
 // dot products: lane j owns output j; column j of a transposed matrix is one LDS bank, the vector
 // element is a broadcast.
 // ---------------------------------------------------------------------------
+// CN > 0: compile-time length (fully unrolled: all LDS reads of a product are issued back to back
+// instead of one exposed LDS latency per 4 MACs)
+template <int CN>
 __device__ __forceinline__ float dot_lds(const float* __restrict__ Wt, int Hd, int j,
                                          const float* __restrict__ v, int n_in) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int i = 0; i < n_in; i += 4) {
+  const int n = CN > 0 ? CN : n_in;
+#pragma unroll
+  for (int i = 0; i < n; i += 4) {
     const float4 x = *reinterpret_cast<const float4*>(v + i);
     s0 += Wt[(i + 0) * Hd + j] * x.x;
     s1 += Wt[(i + 1) * Hd + j] * x.y;
@@ -385,17 +390,23 @@ __device__ __forceinline__ float dot_lds(const float* __restrict__ Wt, int Hd, i
   return (s0 + s1) + (s2 + s3);
 }
 
+template <int CF, int CH>
 __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, int nn_max) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int t = blockIdx.x, g = blockIdx.y;
   const TreeW& w = p.w[g];
-  const int F = p.F, Hd = p.Hd;
+  const int F = CF > 0 ? CF : p.F, Hd = CH > 0 ? CH : p.Hd;
   const int FH = F > Hd ? F : Hd;
   float* R = sm;                       // 3 matrices of one kind: [3][FH][Hd]
   float* xt = R + 3 * FH * Hd;         // input terms of the current direction [3][nn_max][Hd]
   float* hl = xt + 3 * nn_max * Hd;    // bottom-up state   [nn_max][Hd]
   float* hdl = hl + nn_max * Hd;       // top-down state    [nn_max][Hd]
   float* wsl = hdl + nn_max * Hd;      // gated sums [nn_max][Hd]; first holds the x rows [nn_max][F]
+  float* bias = wsl + nn_max * FH;     // bz, br, bzd, brd [4][Hd]
+  int* par_l = (int*)(bias + 4 * Hd);  // parent (local id) [nn_max]
+  int* coff_l = par_l + nn_max;        // child list offsets (local) [nn_max + 1]
+  int* cidx_l = coff_l + nn_max + 1;   // children (local ids) [nn_max]
+  __shared__ int lo_s[TRACE_TREE_MAX_LEVELS + 2];
   const long long ldx = (long long)p.G * F, ldh = (long long)p.G * Hd;
   const int vb = p.tree_off[t];
   const int nn = p.tree_off[t + 1] - vb;
@@ -409,8 +420,28 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
     return;
   }
   const int nl = p.n_levels[t];
-  const int32_t* lo = p.level_off + (long long)t * (TRACE_TREE_MAX_LEVELS + 1);
   const float* xg = p.x + (long long)g * F;
+  // the tree's topology and the gate biases are read on every step of the dependent chain: keep them
+  // in LDS (a global load per level would put an L2 round trip on the critical path each time)
+  {
+    const int32_t* lo_g = p.level_off + (long long)t * (TRACE_TREE_MAX_LEVELS + 1);
+    const int cbase = p.child_off[vb];
+    for (int i = threadIdx.x; i <= TRACE_TREE_MAX_LEVELS; i += blockDim.x) lo_s[i] = lo_g[i] - vb;
+    for (int i = threadIdx.x; i < nn; i += blockDim.x) {
+      const int pg = p.parent[vb + i];
+      par_l[i] = pg < 0 ? -1 : pg - vb;
+    }
+    for (int i = threadIdx.x; i <= nn; i += blockDim.x) coff_l[i] = p.child_off[vb + i] - cbase;
+    const int nch = p.child_off[vb + nn] - cbase;   // <= nn - 1 edges
+    for (int i = threadIdx.x; i < nch && i < nn_max; i += blockDim.x) cidx_l[i] = p.child_idx[cbase + i] - vb;
+    for (int i = threadIdx.x; i < Hd; i += blockDim.x) {
+      bias[i] = w.bz[i];
+      bias[Hd + i] = w.br[i];
+      bias[2 * Hd + i] = w.bzd[i];
+      bias[3 * Hd + i] = w.brd[i];
+    }
+  }
+  const int* lo = lo_s;
 
   auto stage3 = [&](const float* a0, const float* a1, const float* a2, int rows) {
     const float* srcs[3] = {a0, a1, a2};
@@ -430,7 +461,7 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
     for (int idx = threadIdx.x; idx < 3 * nn * Hd; idx += blockDim.x) {
       const int k = idx / (nn * Hd), r = idx - k * nn * Hd;
       const int v = r / Hd, j = r - v * Hd;
-      xt[(k * nn_max + v) * Hd + j] = dot_lds(R + k * FH * Hd, Hd, j, wsl + v * F, F);
+      xt[(k * nn_max + v) * Hd + j] = dot_lds<CF>(R + k * FH * Hd, Hd, j, wsl + v * F, F);
     }
     __syncthreads();
   };
@@ -445,7 +476,7 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
   input_terms(w.Wz, w.Wr, w.Wh);
   stage3(w.Uz, w.Ur, w.Uh, Hd);
   {  // leaves (:289-292): no bias on the leaf gates, as the reference
-    const int v0 = lo[0] - vb, cnt = (lo[1] - lo[0]) * Hd;
+    const int v0 = lo[0], cnt = (lo[1] - lo[0]) * Hd;
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
       const float z = sigmoidf_(xz[v * Hd + j]);
@@ -455,15 +486,15 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
   }
   __syncthreads();
   for (int l = 1; l < nl; ++l) {
-    const int v0 = lo[l] - vb, cnt = (lo[l + 1] - lo[l]) * Hd;
+    const int v0 = lo[l], cnt = (lo[l + 1] - lo[l]) * Hd;
     // phase A: ws = sum_c sigmoid(Wr x + Ur h_c + br) * h_c ; hsum kept in hdl (free until top-down)
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
-      const float a = xr[v * Hd + j] + w.br[j];
+      const float a = xr[v * Hd + j] + bias[Hd + j];
       float fa = 0.f, hs = 0.f;
-      for (int ci = p.child_off[vb + v]; ci < p.child_off[vb + v + 1]; ++ci) {
-        const float* hc = hl + (p.child_idx[ci] - vb) * Hd;
-        fa += sigmoidf_(a + dot_lds(Ur, Hd, j, hc, Hd)) * hc[j];
+      for (int ci = coff_l[v]; ci < coff_l[v + 1]; ++ci) {
+        const float* hc = hl + cidx_l[ci] * Hd;
+        fa += sigmoidf_(a + dot_lds<CH>(Ur, Hd, j, hc, Hd)) * hc[j];
         hs += hc[j];
       }
       wsl[v * Hd + j] = fa;
@@ -473,8 +504,8 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
       const float hs = hdl[v * Hd + j];
-      const float z = sigmoidf_(xz[v * Hd + j] + w.bz[j] + dot_lds(Uz, Hd, j, hdl + v * Hd, Hd));
-      const float c = tanhf(xh[v * Hd + j] + dot_lds(Uh, Hd, j, wsl + v * Hd, Hd));
+      const float z = sigmoidf_(xz[v * Hd + j] + bias[j] + dot_lds<CH>(Uz, Hd, j, hdl + v * Hd, Hd));
+      const float c = tanhf(xh[v * Hd + j] + dot_lds<CH>(Uh, Hd, j, wsl + v * Hd, Hd));
       hl[v * Hd + j] = z * hs + (1.0f - z) * c;
     }
     __syncthreads();
@@ -486,24 +517,24 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
   input_terms(w.Wzd, w.Wrd, w.Whd);
   stage3(w.Uzd, w.Urd, w.Uhd, Hd);
   {
-    const int v0 = lo[nl - 1] - vb, cnt = (lo[nl] - lo[nl - 1]) * Hd;
+    const int v0 = lo[nl - 1], cnt = (lo[nl] - lo[nl - 1]) * Hd;
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) hdl[v0 * Hd + idx] = hl[v0 * Hd + idx];  // roots copy h
   }
   __syncthreads();
   for (int l = nl - 2; l >= 0; --l) {
-    const int v0 = lo[l] - vb, cnt = (lo[l + 1] - lo[l]) * Hd;
+    const int v0 = lo[l], cnt = (lo[l + 1] - lo[l]) * Hd;
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
-      const float* hf = hdl + (p.parent[vb + v] - vb) * Hd;
-      const float r = sigmoidf_(xr[v * Hd + j] + dot_lds(Ur, Hd, j, hf, Hd) + w.brd[j]);
+      const float* hf = hdl + par_l[v] * Hd;
+      const float r = sigmoidf_(xr[v * Hd + j] + dot_lds<CH>(Ur, Hd, j, hf, Hd) + bias[3 * Hd + j]);
       wsl[v * Hd + j] = r * hf[j];
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < cnt; idx += blockDim.x) {
       const int v = v0 + idx / Hd, j = idx % Hd;
-      const float* hf = hdl + (p.parent[vb + v] - vb) * Hd;
-      const float z = sigmoidf_(xz[v * Hd + j] + dot_lds(Uz, Hd, j, hf, Hd) + w.bzd[j]);
-      const float c = tanhf(xh[v * Hd + j] + dot_lds(Uh, Hd, j, wsl + v * Hd, Hd));
+      const float* hf = hdl + par_l[v] * Hd;
+      const float z = sigmoidf_(xz[v * Hd + j] + dot_lds<CH>(Uz, Hd, j, hf, Hd) + bias[2 * Hd + j]);
+      const float c = tanhf(xh[v * Hd + j] + dot_lds<CH>(Uh, Hd, j, wsl + v * Hd, Hd));
       hdl[v * Hd + j] = z * hf[j] + (1.0f - z) * c;
     }
     __syncthreads();
@@ -589,17 +620,25 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
   // LDS-resident pass when the caller bounds the tree size and one direction fits (see the kernel)
   if (max_tree_nodes > 0) {
     const int FH = F > Hd ? F : Hd;
-    const size_t need = ((size_t)3 * FH * Hd + (size_t)max_tree_nodes * (6 * Hd + (F > Hd ? F - Hd : 0))) * sizeof(float);  // xt(3) + h + hd + ws|x
+    const size_t need = ((size_t)3 * FH * Hd + (size_t)max_tree_nodes * (6 * Hd + (F > Hd ? F - Hd : 0)) + 4 * Hd + 3 * (size_t)max_tree_nodes + 4) *
+                        sizeof(float);  // xt(3) + h + hd + ws|x, biases, topology
     if (need <= 156 * 1024) {
       static bool attr2 = false;
       if (!attr2) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel<0, 0>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel<64, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr2 = true;
       }
-      hipLaunchKernelGGL(tree_gru_lds_kernel, dim3(n_trees, n_groups), dim3(256), need, (hipStream_t)stream, p,
-                         max_tree_nodes);
+      if (F == 64 && Hd == 64)
+        hipLaunchKernelGGL((tree_gru_lds_kernel<64, 64>), dim3(n_trees, n_groups), dim3(256), need,
+                           (hipStream_t)stream, p, max_tree_nodes);
+      else
+        hipLaunchKernelGGL((tree_gru_lds_kernel<0, 0>), dim3(n_trees, n_groups), dim3(256), need,
+                           (hipStream_t)stream, p, max_tree_nodes);
       return check_launch("tree_gru");
     }
   }
