@@ -104,6 +104,15 @@ int trace_nms(const float* boxes, const float* scores, int N, float thresh,
               int mode, int64_t* keep_out, int32_t* num_keep, void* workspace,
               size_t workspace_bytes, trace_stream_t stream);
 
+/* Per-class NMS of one image in ONE pass — lib/modeling_rel/model_builder_rel.py:1286-1313
+ * (the `for j in range(1, num_classes)` loop around box_utils.nms): boxes of different `group`
+ * (class) never suppress each other; within a group the result equals trace_nms on that group's
+ * boxes alone.  keep_out: kept ORIGINAL indices ascending. */
+int trace_nms_grouped(const float* boxes, const float* scores, const int32_t* group,
+                      int N, float thresh, int mode, int64_t* keep_out,
+                      int32_t* num_keep, void* workspace, size_t workspace_bytes,
+                      trace_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* Box helpers                                                               */
 /* ------------------------------------------------------------------------ */
@@ -113,6 +122,15 @@ int trace_nms(const float* boxes, const float* scores, int N, float thresh,
 int trace_fpn_levels(const float* boxes, int N, int k_min, int k_max,
                      float canonical_scale, float canonical_level,
                      float* levels, trace_stream_t stream);
+
+/* utils.boxes.bbox_transform + clip_tiled_boxes — Detectron_pytorch/lib/utils/boxes.py:160-200,
+ * 142-157 (called from model_builder_rel.py:1261-1278 get_det_boxes).  boxes (R,4), deltas (R,4K)
+ * -> out (R,4K) decoded with weights (wx,wy,ww,wh), dw/dh clipped at xform_clip
+ * (cfg.BBOX_XFORM_CLIP = log(1000/16)), clipped to [0,im_w-1] x [0,im_h-1]. */
+int trace_bbox_transform_clip(const float* boxes, const float* deltas, int R, int K,
+                              float wx, float wy, float ww, float wh,
+                              float xform_clip, float im_h, float im_w, float* out,
+                              trace_stream_t stream);
 
 /* cython_bbox.bbox_overlaps — Detectron_pytorch/lib/utils/cython_bbox.pyx:32-73.
  * boxes (N,4), query (K,4) -> overlaps (N,K) f32. */

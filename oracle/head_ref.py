@@ -10,9 +10,16 @@ lib/combine_tree/cluster_tree.py:163-352, lib/i3d/box_head3d.py:53-79 and
 lib/modeling_rel/fast_rcnn_heads.py:15-51,94-152.
 
 The three 2-D / 3-D conv bodies are outside this function: their outputs (blob_conv,
-feat_map, temporal maps) are inputs.  The reference's Python cannot be imported in the build
-container (torch._six / mmcv / torchvision / cv2 / Cython extensions absent), so this
-restatement is PARITY UNPINNED by execution; ROIAlign inside it is the pinned C oracle.
+feat_map, temporal maps) are inputs.
+
+Pinning: the stages below are checked against outputs of the reference's own modules run on the CPU
+of the build container (tools/make_goldens_py.py -> tests/golden/py_heads.npz, py_cluster_tree3d.npz,
+py_pair_head.npz; tests/test_oracle_goldens_py.py): roi_2mlp_head / fast_rcnn_outputs / Tail_Layer_3D,
+the whole cluster_tree3d.forward (temporal ROIAlign order, attention, region tree, tree-GRU, FFN),
+get_spatio_atten_feat and get_sem_feat.  ROIAlign inside is the pinned C oracle.  NOT pinned by
+execution (Generalized_RCNN() itself cannot be constructed here: mmcv, GloVe and the dataset
+statistics are absent): the glue of `_forward` between those stages (:938-952, :1018-1024,
+:1039-1042, :1064-1083), restated line by line.
 """
 import math
 
@@ -108,6 +115,75 @@ def _tree_gru(sd, prefix, feat, layers, n_tree, A, A_T):
     return _lin(sd, prefix + ".FFN1.0", h) + _lin(sd, prefix + ".FFN2.0", hd)
 
 
+def cluster_tree3d_forward(sd, prefix, roi, feat_map, obj_feat_vec, tmaps, low_dim=256, groups=4,
+                           max_tree_height=7, partition=2, rel_scale=1.0 / 16):
+    """cluster_tree3d.forward for one clip, lib/combine_tree/cluster_tree3d.py:114-335.
+      roi (n,5) f32 [0,x1,y1,x2,y2]; feat_map (1,C,h,w); obj_feat_vec (n,K); tmaps (T',C,h,w); static tubes
+      (model_builder_rel.py:1441-1444: temporal_roi = roi repeated over T')."""
+    P = prefix + "."
+    n = roi.shape[0]
+    Tn = tmaps.shape[0]
+    boxes = np.ascontiguousarray(roi[:, 1:5], np.float32)
+    t_rois = temporal_rois(boxes, Tn, n)
+    t_pool = _roi_align(tmaps, t_rois, rel_scale, 0)                      # :169-173
+    t_feat = _tail(sd, P + "temporal_obj_fc", t_pool)                     # :186
+    t_feat = t_feat.view(Tn, n, -1).permute(1, 0, 2).contiguous()         # :181-182,187
+    att = _temporal_attention(sd, P + "temporal_obj_atten", obj_feat_vec, t_feat, low_dim)  # :192
+    obj_agg = obj_feat_vec + _feat_val(sd, P + "temporal_obj_feat_val", att)  # :195,201
+    layers, tree = np_oracle.node_cluster(boxes, max_tree_height, partition)  # :205-214
+    n_tree = tree.shape[0]
+    m = n_tree - n
+    A, A_T, link = np_oracle.get_A_and_link(n_tree, layers)               # :219
+    reg_boxes = tree[n:].astype(np.float32)
+    reg_rois = np.concatenate([np.zeros((m, 1), np.float32), reg_boxes], 1)
+    reg_map = _roi_align(feat_map, reg_rois, rel_scale, 0)                # :238-242
+    reg_feat = _lin(sd, P + "fc_r.2", F.relu(_lin(sd, P + "fc_r.0", reg_map.reshape(m, -1))))  # :244
+    t_boxes = np.repeat(boxes[:, None, :], Tn, axis=1)
+    t_reg = np_oracle.temporal_nonleaf_rois(layers, n_tree, n, t_boxes)   # :247-251 (m,T,4)
+    tr_rois = np.concatenate([np.repeat(np.arange(Tn), m).astype(np.float32)[:, None], t_reg.reshape(-1, 4)], 1)
+    tr_pool = _roi_align(tmaps, tr_rois, rel_scale, 0)                    # :268-272
+    tr_feat = _tail(sd, P + "temporal_r_fc", tr_pool).view(Tn, m, -1).permute(1, 0, 2).contiguous()
+    att_r = _temporal_attention(sd, P + "temporal_r_atten", reg_feat, tr_feat, low_dim)  # :293
+    reg_agg = reg_feat + _feat_val(sd, P + "temporal_r_feat_val", att_r)  # :297,305
+    r2c = _lin(sd, P + "r2c.1", F.relu(reg_agg))                          # :307
+    o2c = _lin(sd, P + "o2c.1", F.relu(obj_agg))                          # :308
+    pooled_features = torch.cat([o2c, r2c], 0)                            # :310-316
+    gw = pooled_features.shape[1] // groups
+    agg = [_tree_gru(sd, P + "tree_message_passing_list.%d" % g, pooled_features[:, gw * g:gw * (g + 1)],
+                     layers, n_tree, A, A_T) for g in range(groups)]      # :319-327
+    pooled_features = _lin(sd, P + "FFN.1", F.relu(torch.cat(agg, 1)))    # :330
+    return dict(pooled_features=pooled_features, region_map=reg_map, layers=layers, tree_boxes=tree, A=A, A_T=A_T,
+                link=link, obj_agg=obj_agg, reg_agg=reg_agg, nonleaf_rois=reg_rois)
+
+
+def pair_attention(sd, roi, feat_map, obj_feature, link, sbj_inds, obj_inds, rel_scale=1.0 / 16):
+    """get_spatio_atten_feat for one clip, lib/modeling_rel/model_builder_rel.py:1524-1612.
+    Returns s_map, o_map, v_map (P,K,7,7), lca as REGION index (:1559), union rois, q_s, q_o."""
+    n = roi.shape[0]
+    q_s = _lin(sd, "spatio_atten_s.1", F.leaky_relu(obj_feature, 0.1))    # :1540
+    q_o = _lin(sd, "spatio_atten_o.1", F.leaky_relu(obj_feature, 0.1))    # :1541
+    v_full = F.conv2d(feat_map, sd["spatio_atten_map.weight"], sd["spatio_atten_map.bias"])  # :1542
+    k_full = F.conv2d(feat_map, sd["atten_q_map.weight"], sd["atten_q_map.bias"])            # :1543
+    lca = np_oracle.get_lca(sbj_inds, obj_inds, link) - n                 # :1553,1559
+    union = np_oracle.rois_union(roi[sbj_inds], roi[obj_inds]).astype(np.float32)  # :1561-1562,1588-1594
+    k_p = _roi_align(k_full, union, rel_scale, 0)                         # :1566
+    v_p = _roi_align(v_full, union, rel_scale, 0)                         # :1568
+
+    def mask_map(q):                                                      # :1596-1612
+        score = (q.view(q.shape[0], q.shape[1], 1, 1) * k_p).sum(1).view(q.shape[0], -1)
+        score = F.softmax(score, 1).view(k_p.shape[0], 1, k_p.shape[2], k_p.shape[3])
+        return v_p * score
+    return mask_map(q_s[sbj_inds]), mask_map(q_o[obj_inds]), v_p, lca, union, q_s, q_o
+
+
+def sem_feat(sd, softmax_obj_vec, region_feature, lca, sbj_inds, obj_inds):
+    """get_sem_feat for one clip, model_builder_rel.py:1643-1668."""
+    low_s = _lin(sd, "sem_s_e.1", F.leaky_relu(_lin(sd, "embed_s", softmax_obj_vec), 0.1))
+    low_o = _lin(sd, "sem_o_e.1", F.leaky_relu(_lin(sd, "embed_o", softmax_obj_vec), 0.1))
+    low_r = _lin(sd, "sem_r.1", F.leaky_relu(region_feature, 0.1))
+    return low_s[sbj_inds] + low_r[lca] + low_o[obj_inds]
+
+
 def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale=1.0, groups=4,
                  low_dim=256, max_tree_height=7, partition=2, conv_scale=1.0 / 16, rel_scale=1.0 / 16):
     """One clip.
@@ -138,63 +214,21 @@ def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale
     roi[:, 1:5] *= float(1.0 * f_scale * (1.0 / im_scale))
     roi = roi.astype(np.float32)
     boxes = roi[:, 1:5]
-    # ---- cluster_tree3d.forward (cluster_tree3d.py:114-335)
-    t_rois = temporal_rois(boxes, Tn, n)
-    t_pool = _roi_align(tmaps, t_rois, rel_scale, 0)                      # :169-173
-    t_feat = _tail(sd, "cluster_tree3d.temporal_obj_fc", t_pool)          # :186
-    t_feat = t_feat.view(Tn, n, -1).permute(1, 0, 2).contiguous()         # :181-182,187
-    att = _temporal_attention(sd, "cluster_tree3d.temporal_obj_atten", det_feat, t_feat, low_dim)  # :192
-    obj_agg = det_feat + _feat_val(sd, "cluster_tree3d.temporal_obj_feat_val", att)  # :195,201
-    layers, tree = np_oracle.node_cluster(boxes, max_tree_height, partition)  # :205-214
-    n_tree = tree.shape[0]
-    m = n_tree - n
-    A, A_T, link = np_oracle.get_A_and_link(n_tree, layers)               # :219
-    reg_boxes = tree[n:].astype(np.float32)
-    reg_rois = np.concatenate([np.zeros((m, 1), np.float32), reg_boxes], 1)
-    reg_map = _roi_align(feat_map, reg_rois, rel_scale, 0)                # :238-242
-    reg_feat = _lin(sd, "cluster_tree3d.fc_r.2", F.relu(_lin(sd, "cluster_tree3d.fc_r.0", reg_map.reshape(m, -1))))  # :244
-    t_boxes = np.repeat(boxes[:, None, :], Tn, axis=1)
-    t_reg = np_oracle.temporal_nonleaf_rois(layers, n_tree, n, t_boxes)   # :247-251 (m,T,4)
-    tr_rois = np.concatenate([np.repeat(np.arange(Tn), m).astype(np.float32)[:, None], t_reg.reshape(-1, 4)], 1)
-    tr_pool = _roi_align(tmaps, tr_rois, rel_scale, 0)                    # :268-272
-    tr_feat = _tail(sd, "cluster_tree3d.temporal_r_fc", tr_pool).view(Tn, m, -1).permute(1, 0, 2).contiguous()
-    att_r = _temporal_attention(sd, "cluster_tree3d.temporal_r_atten", reg_feat, tr_feat, low_dim)  # :293
-    reg_agg = reg_feat + _feat_val(sd, "cluster_tree3d.temporal_r_feat_val", att_r)  # :297,305
-    r2c = _lin(sd, "cluster_tree3d.r2c.1", F.relu(reg_agg))               # :307
-    o2c = _lin(sd, "cluster_tree3d.o2c.1", F.relu(obj_agg))               # :308
-    pooled_features = torch.cat([o2c, r2c], 0)                            # :310-316
-    gw = pooled_features.shape[1] // groups
-    agg = [_tree_gru(sd, "cluster_tree3d.tree_message_passing_list.%d" % g, pooled_features[:, gw * g:gw * (g + 1)],
-                     layers, n_tree, A, A_T) for g in range(groups)]      # :319-327
-    pooled_features = _lin(sd, "cluster_tree3d.FFN.1", F.relu(torch.cat(agg, 1)))  # :330
+    ct = cluster_tree3d_forward(sd, "cluster_tree3d", roi, feat_map, det_feat, tmaps, low_dim=low_dim, groups=groups,
+                                max_tree_height=max_tree_height, partition=partition, rel_scale=rel_scale)
+    pooled_features, layers, tree, link = ct["pooled_features"], ct["layers"], ct["tree_boxes"], ct["link"]
+    obj_agg, reg_agg = ct["obj_agg"], ct["reg_agg"]
     # ---- back in _forward (:1018-1024)
     obj_feature = det_feat + _lin(sd, "restore_obj_feat.1", F.leaky_relu(pooled_features[:n], 0.1))
     region_feature = pooled_features[n:]
     obj_score = F.softmax(_lin(sd, "cem_Box_Outs.cls_score", F.relu(obj_feature)), dim=1)  # :1024,1084
-    # ---- target-adaptive pair attention (:1524-1612)
-    q_s = _lin(sd, "spatio_atten_s.1", F.leaky_relu(obj_feature, 0.1))
-    q_o = _lin(sd, "spatio_atten_o.1", F.leaky_relu(obj_feature, 0.1))
-    v_full = F.conv2d(feat_map, sd["spatio_atten_map.weight"], sd["spatio_atten_map.bias"])
-    k_full = F.conv2d(feat_map, sd["atten_q_map.weight"], sd["atten_q_map.bias"])
-    lca = np_oracle.get_lca(sbj_inds, obj_inds, link) - n                 # :1553,1559 (region index)
-    union = np_oracle.rois_union(roi[sbj_inds], roi[obj_inds]).astype(np.float32)  # :1561-1562,1588-1594
-    k_p = _roi_align(k_full, union, rel_scale, 0)                         # :1566
-    v_p = _roi_align(v_full, union, rel_scale, 0)                         # :1568
-
-    def mask_map(q):                                                      # :1596-1612
-        score = (q.view(q.shape[0], q.shape[1], 1, 1) * k_p).sum(1).view(q.shape[0], -1)
-        score = F.softmax(score, 1).view(k_p.shape[0], 1, k_p.shape[2], k_p.shape[3])
-        return v_p * score
-    s_map, o_map = mask_map(q_s[sbj_inds]), mask_map(q_o[obj_inds])
+    s_map, o_map, v_p, lca, union, q_s, q_o = pair_attention(sd, roi, feat_map, obj_feature, link, sbj_inds, obj_inds,
+                                                             rel_scale=rel_scale)
     sp = F.leaky_relu(F.conv2d(s_map, sd["spatio_inferA.0.weight"], sd["spatio_inferA.0.bias"]) +
                       F.conv2d(o_map, sd["spatio_inferB.0.weight"], sd["spatio_inferB.0.bias"]), 0.1)  # :1039
     sp = (sp + v_p).view(sp.shape[0], -1)                                 # :1040-1041
     spatio_infer = _lin(sd, "spatio_infer_fc.0", sp)                      # :1042
-    # ---- semantic branch (:1643-1668)
-    low_s = _lin(sd, "sem_s_e.1", F.leaky_relu(_lin(sd, "embed_s", cls), 0.1))
-    low_o = _lin(sd, "sem_o_e.1", F.leaky_relu(_lin(sd, "embed_o", cls), 0.1))
-    low_r = _lin(sd, "sem_r.1", F.leaky_relu(region_feature, 0.1))
-    sem = low_s[sbj_inds] + low_r[lca] + low_o[obj_inds]
+    sem = sem_feat(sd, cls, region_feature, lca, sbj_inds, obj_inds)      # :1044
     # ---- scoring (:1064-1083)
     s_lab = torch.from_numpy(det_labels[sbj_inds].astype(np.int64) - 1)
     o_lab = torch.from_numpy(det_labels[obj_inds].astype(np.int64) - 1)

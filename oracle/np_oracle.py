@@ -1,9 +1,10 @@
 """TEST INFRASTRUCTURE ONLY — numpy restatements of the reference's numpy glue.
 
-The reference's Python cannot be imported in the build container (torch._six,
-mmcv, torchvision, cv2 and the Cython extensions are absent), so these follow
-the cited source lines expression by expression; they are pinned only by that
-construction ("parity unpinned" by execution).
+Pinned by execution: tests/golden/py_box_glue.npz, py_tree.npz and py_relpn.npz hold outputs of the
+reference's own functions (run on the CPU of the build container by tools/make_goldens_py.py) and
+tests/test_oracle_goldens_py.py checks every function here against them bit for bit.  Not reachable
+that way (Cython sources do not build here): bbox_overlaps / bbox_pair_overlaps / the overlap filter
+and box_results_with_nms_and_limit, which follow the cited lines only.
 """
 import math
 
@@ -45,6 +46,48 @@ def add_multilevel_roi_blobs(blobs, blob_prefix, rois, target_lvls, lvl_min, lvl
     return blobs
 
 
+def bbox_transform(boxes, deltas, weights=(1.0, 1.0, 1.0, 1.0), xform_clip=math.log(1000. / 16.)):
+    """Detectron_pytorch/lib/utils/boxes.py:160-200 (cfg.BBOX_XFORM_CLIP = log(1000/16))."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0, deltas.shape[1]), dtype=deltas.dtype)
+    boxes = boxes.astype(deltas.dtype, copy=False)
+    widths = boxes[:, 2] - boxes[:, 0] + 1.0
+    heights = boxes[:, 3] - boxes[:, 1] + 1.0
+    ctr_x = boxes[:, 0] + 0.5 * widths
+    ctr_y = boxes[:, 1] + 0.5 * heights
+    wx, wy, ww, wh = weights
+    dx = deltas[:, 0::4] / wx
+    dy = deltas[:, 1::4] / wy
+    dw = deltas[:, 2::4] / ww
+    dh = deltas[:, 3::4] / wh
+    dw = np.minimum(dw, xform_clip)
+    dh = np.minimum(dh, xform_clip)
+    pred_ctr_x = dx * widths[:, np.newaxis] + ctr_x[:, np.newaxis]
+    pred_ctr_y = dy * heights[:, np.newaxis] + ctr_y[:, np.newaxis]
+    pred_w = np.exp(dw) * widths[:, np.newaxis]
+    pred_h = np.exp(dh) * heights[:, np.newaxis]
+    pred_boxes = np.zeros(deltas.shape, dtype=deltas.dtype)
+    pred_boxes[:, 0::4] = pred_ctr_x - 0.5 * pred_w
+    pred_boxes[:, 1::4] = pred_ctr_y - 0.5 * pred_h
+    pred_boxes[:, 2::4] = pred_ctr_x + 0.5 * pred_w - 1
+    pred_boxes[:, 3::4] = pred_ctr_y + 0.5 * pred_h - 1
+    return pred_boxes
+
+
+def clip_tiled_boxes(boxes, im_shape):
+    """Detectron_pytorch/lib/utils/boxes.py:142-157."""
+    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], im_shape[1] - 1), 0)
+    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], im_shape[0] - 1), 0)
+    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], im_shape[1] - 1), 0)
+    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], im_shape[0] - 1), 0)
+    return boxes
+
+
+def argsort_desc(scores):
+    """lib/datasets_rel/pytorch_misc.py:28-35."""
+    return np.column_stack(np.unravel_index(np.argsort(-scores.ravel()), scores.shape))
+
+
 def rois_union(rois1, rois2):
     """lib/utils_rel/boxes_rel.py:100-106."""
     assert (rois1[:, 0] == rois2[:, 0]).all()
@@ -55,18 +98,31 @@ def rois_union(rois1, rois2):
     return np.vstack((rois1[:, 0], xmin, ymin, xmax, ymax)).transpose()
 
 
-def relpn_pairs(det_rois):
-    """lib/modeling_rel/relpn_heads.py:79-88,117 (+ remove_self_pairs :39-46)."""
+def relpn_pairs(det_rois, det_labels=None, dataset_name="vidvrd"):
+    """lib/modeling_rel/relpn_heads.py:71-88,117 (+ remove_self_pairs :39-46,
+    sbj_adapt_remove_self_pairs :48-55: on Action Genome only persons, label <= 1, are subjects)."""
     n = det_rois.shape[0]
-    sbj_inds = np.repeat(np.arange(n), n)
-    obj_inds = np.tile(np.arange(n), n)
-    if n > 1:
-        mask = np.ones(sbj_inds.shape[0], dtype=bool)
-        for i in range(n):
-            mask[i + n * i] = False
-        keeps = np.where(mask)[0]
-        sbj_inds = sbj_inds[keeps]
-        obj_inds = obj_inds[keeps]
+    person_inds = np.where(det_labels <= 1)[0] if det_labels is not None else np.zeros((0,), np.int64)
+    if dataset_name.find('ag') >= 0 and len(person_inds) > 0:
+        sbj_inds = np.repeat(person_inds, n)
+        obj_inds = np.tile(np.arange(n), person_inds.shape[0])
+        if n > 1:
+            mask = np.ones(sbj_inds.shape[0], dtype=bool)
+            for i in range(person_inds.shape[0]):
+                mask[person_inds[i] + n * i] = False
+            keeps = np.where(mask)[0]
+            sbj_inds = sbj_inds[keeps]
+            obj_inds = obj_inds[keeps]
+    else:
+        sbj_inds = np.repeat(np.arange(n), n)
+        obj_inds = np.tile(np.arange(n), n)
+        if n > 1:
+            mask = np.ones(sbj_inds.shape[0], dtype=bool)
+            for i in range(n):
+                mask[i + n * i] = False
+            keeps = np.where(mask)[0]
+            sbj_inds = sbj_inds[keeps]
+            obj_inds = obj_inds[keeps]
     sbj_rois = det_rois[sbj_inds]
     obj_rois = det_rois[obj_inds]
     rel_rois = rois_union(sbj_rois, obj_rois)

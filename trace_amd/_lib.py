@@ -36,6 +36,8 @@ SIGNATURES = {
     "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
+    "trace_nms_grouped": (c_int, [P, P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
+    "trace_bbox_transform_clip": (c_int, [P, P, c_int, c_int] + [c_float] * 7 + [P, P]),
     "trace_fpn_levels": (c_int, [P, c_int, c_int, c_int, c_float, c_float, P, P]),
     "trace_bbox_overlaps": (c_int, [P, c_int, P, c_int, P, P]),
     "trace_bbox_pair_overlaps": (c_int, [P, P, c_int, P, P]),

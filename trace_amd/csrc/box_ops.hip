@@ -101,6 +101,33 @@ __global__ __launch_bounds__(256) void relpn_pairs_kernel(const float* __restric
   rel[p * 5 + 4] = fmaxf(a[4], b[4]);
 }
 
+// utils/boxes.py:160-200 bbox_transform followed by :142-157 clip_tiled_boxes: one thread per
+// (roi, class) box.  deltas (R, 4*K); boxes (R,4); out (R, 4*K).
+__global__ __launch_bounds__(256) void bbox_transform_clip_kernel(const float* __restrict__ boxes,
+                                                                  const float* __restrict__ deltas, int R, int K,
+                                                                  float wx, float wy, float ww, float wh,
+                                                                  float xform_clip, float im_h, float im_w,
+                                                                  float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * K) return;
+  const int r = idx / K;
+  const float* b = boxes + (long long)r * 4;
+  const float* d = deltas + (long long)idx * 4;
+  const float width = b[2] - b[0] + 1.0f, height = b[3] - b[1] + 1.0f;
+  const float ctr_x = b[0] + 0.5f * width, ctr_y = b[1] + 0.5f * height;
+  const float dx = d[0] / wx, dy = d[1] / wy;
+  const float dw = fminf(d[2] / ww, xform_clip), dh = fminf(d[3] / wh, xform_clip);
+  const float pcx = dx * width + ctr_x, pcy = dy * height + ctr_y;
+  const float pw = expf(dw) * width, ph = expf(dh) * height;
+  float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph;
+  float x2 = pcx + 0.5f * pw - 1.0f, y2 = pcy + 0.5f * ph - 1.0f;
+  x1 = fmaxf(fminf(x1, im_w - 1.0f), 0.f);
+  y1 = fmaxf(fminf(y1, im_h - 1.0f), 0.f);
+  x2 = fmaxf(fminf(x2, im_w - 1.0f), 0.f);
+  y2 = fmaxf(fminf(y2, im_h - 1.0f), 0.f);
+  *reinterpret_cast<float4*>(out + (long long)idx * 4) = make_float4(x1, y1, x2, y2);
+}
+
 }  // namespace trace
 
 using namespace trace;
@@ -146,4 +173,17 @@ extern "C" int trace_relpn_pairs(const float* det_rois, int n, int32_t* sbj_inds
   hipLaunchKernelGGL(relpn_pairs_kernel, dim3(ceil_div(P, 256)), dim3(256), 0, (hipStream_t)stream,
                      det_rois, n, P, sbj_inds, obj_inds, rel_rois);
   return check_launch("relpn_pairs");
+}
+
+extern "C" int trace_bbox_transform_clip(const float* boxes, const float* deltas, int R, int K, float wx,
+                                         float wy, float ww, float wh, float xform_clip, float im_h,
+                                         float im_w, float* out, trace_stream_t stream) {
+  TRACE_REQUIRE(R >= 0 && K > 0, "bbox_transform_clip: bad shape R=%d K=%d", R, K);
+  if (R == 0) return 0;
+  TRACE_REQUIRE(boxes && deltas && out, "bbox_transform_clip: null pointer");
+  TRACE_REQUIRE(((uintptr_t)out & 15) == 0, "bbox_transform_clip: out must be 16-byte aligned");
+  const long long n = (long long)R * K;
+  hipLaunchKernelGGL(bbox_transform_clip_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, boxes, deltas, R, K, wx, wy, ww, wh, xform_clip, im_h, im_w, out);
+  return check_launch("bbox_transform_clip");
 }

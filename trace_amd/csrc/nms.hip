@@ -19,7 +19,7 @@
 
 namespace trace {
 
-constexpr int NMS_MAX_BOXES = 8192;  // 64 KiB of LDS for the sort; 128 mask words per row
+constexpr int NMS_MAX_BOXES = 16384;  // 128 KiB of LDS for the sort; 256 mask words per row (4 per lane)
 
 struct NmsWorkspace {
   int32_t* order;   // [Npad64] sorted -> original index
@@ -27,6 +27,7 @@ struct NmsWorkspace {
   float* sareas;    // [Npad64]
   uint64_t* mask;   // [Npad64 * col_blocks]
   int32_t* keep;    // [Npad64] flag per ORIGINAL index
+  int32_t* sgroup;  // [Npad64] group id in sorted order (grouped NMS)
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -46,7 +47,9 @@ static size_t carve(int N, void* base, NmsWorkspace* ws) {
   void* sareas = take(npad * sizeof(float));
   void* mask = take(npad * col_blocks * sizeof(uint64_t));
   void* keep = take(npad * sizeof(int32_t));
+  void* sgroup = take(npad * sizeof(int32_t));
   if (ws) {
+    ws->sgroup = (int32_t*)sgroup;
     ws->order = (int32_t*)order;
     ws->sboxes = (float4*)sboxes;
     ws->sareas = (float*)sareas;
@@ -65,7 +68,9 @@ __device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) {
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes,
                                                         const float* __restrict__ scores, int N,
                                                         int npow2, int npad, int32_t* order,
-                                                        float4* sboxes, float* sareas) {
+                                                        float4* sboxes, float* sareas,
+                                                        const int32_t* __restrict__ group,
+                                                        int32_t* sgroup) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* key = (float*)smem;
   int* idx = (int*)(smem + (size_t)npow2 * sizeof(float));
@@ -107,7 +112,9 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
             y2 = boxes[o * 4 + 3];
       sboxes[i] = make_float4(x1, y1, x2, y2);
       sareas[i] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);  // cython_nms.pyx:44
+      sgroup[i] = group ? group[o] : 0;
     } else {
+      sgroup[i] = -1;
       order[i] = -1;
       sboxes[i] = make_float4(0.f, 0.f, -1.f, -1.f);
       sareas[i] = 0.f;
@@ -119,18 +126,22 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sboxes,
                                                       const float* __restrict__ sareas, int N,
                                                       int col_blocks, float thresh, int mode,
+                                                      const int32_t* __restrict__ sgroup,
                                                       uint64_t* __restrict__ mask) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (col_blk < row_blk) return;
   __shared__ float4 cb[64];
   __shared__ float ca[64];
+  __shared__ int cg[64];
   const int lane = threadIdx.x;
   cb[lane] = sboxes[col_blk * 64 + lane];
   ca[lane] = sareas[col_blk * 64 + lane];
+  cg[lane] = sgroup[col_blk * 64 + lane];
   __syncthreads();
   const int row = row_blk * 64 + lane;
   const float4 a = sboxes[row];
   const float aa = sareas[row];
+  const int ag = sgroup[row];
   const int col_size = min(N - col_blk * 64, 64);
   uint64_t t = 0;
   const int start = (row_blk == col_blk) ? lane + 1 : 0;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
       float inter = w * h;
       float ovr = inter / (aa + ca[i] - inter);
       bool sup = (mode == TRACE_NMS_GT) ? (ovr > thresh) : (ovr >= thresh);
-      if (sup) t |= 1ULL << i;
+      if (sup && cg[i] == ag) t |= 1ULL << i;  // boxes of different groups (classes) never interact
     }
   }
   mask[(size_t)row * col_blocks + col_blk] = t;
@@ -238,9 +249,9 @@ extern "C" size_t trace_nms_workspace_bytes(int n_boxes) {
   return carve(n_boxes, nullptr, nullptr);
 }
 
-extern "C" int trace_nms(const float* boxes, const float* scores, int N, float thresh, int mode,
-                         int64_t* keep_out, int32_t* num_keep, void* workspace,
-                         size_t workspace_bytes, trace_stream_t stream) {
+static int nms_launch(const float* boxes, const float* scores, const int32_t* group, int N, float thresh,
+                      int mode, int64_t* keep_out, int32_t* num_keep, void* workspace,
+                      size_t workspace_bytes, trace_stream_t stream) {
   TRACE_REQUIRE(N >= 0, "nms: negative box count %d", N);
   TRACE_REQUIRE(N <= NMS_MAX_BOXES, "nms: %d boxes exceeds the supported maximum %d", N,
                 NMS_MAX_BOXES);
@@ -263,12 +274,36 @@ extern "C" int trace_nms(const float* boxes, const float* scores, int N, float t
   int npow2 = 64;
   while (npow2 < N) npow2 <<= 1;
   size_t lds = (size_t)npow2 * 8;
+  if (lds > 64 * 1024) {
+    static bool attr = false;  // > 64 KiB of dynamic LDS must be opted into once
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_sort_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_BOXES * 8);
+      TRACE_REQUIRE(e == hipSuccess, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr = true;
+    }
+  }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, N, npow2, npad,
-                     ws.order, ws.sboxes, ws.sareas);
+                     ws.order, ws.sboxes, ws.sareas, group, ws.sgroup);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, s, ws.sboxes,
-                     ws.sareas, N, col_blocks, thresh, mode, ws.mask);
+                     ws.sareas, N, col_blocks, thresh, mode, ws.sgroup, ws.mask);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, ws.mask, ws.order, N, col_blocks,
                      ws.keep);
   hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, s, ws.keep, N, keep_out, num_keep);
   return check_launch("nms");
+}
+
+extern "C" int trace_nms(const float* boxes, const float* scores, int N, float thresh, int mode,
+                         int64_t* keep_out, int32_t* num_keep, void* workspace,
+                         size_t workspace_bytes, trace_stream_t stream) {
+  return nms_launch(boxes, scores, nullptr, N, thresh, mode, keep_out, num_keep, workspace, workspace_bytes,
+                    stream);
+}
+
+extern "C" int trace_nms_grouped(const float* boxes, const float* scores, const int32_t* group, int N,
+                                 float thresh, int mode, int64_t* keep_out, int32_t* num_keep,
+                                 void* workspace, size_t workspace_bytes, trace_stream_t stream) {
+  TRACE_REQUIRE(N == 0 || group, "nms_grouped: null group array");
+  return nms_launch(boxes, scores, group, N, thresh, mode, keep_out, num_keep, workspace, workspace_bytes,
+                    stream);
 }
