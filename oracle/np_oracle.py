@@ -262,3 +262,63 @@ def topk_triplets(prd_scores, sbj_scores, obj_scores, prd_k, topk):
     pair = order // prd_k
     slot = order % prd_k
     return flat[order], pair, det_labels_prd[pair, slot]
+
+
+# ---------------------------------------------------------------------------
+# Detected-box branch: lib/modeling_rel/model_builder_rel.py:1212-1340
+# (pinned by tests/golden/py_det_branch.npz)
+# ---------------------------------------------------------------------------
+def box_results_with_nms_and_limit(scores, boxes, num_classes, score_thresh=0.05, nms_thresh=0.5,
+                                   detections_per_im=100, nms_fn=None):
+    """model_builder_rel.py:1280-1340 (soft-NMS and box voting disabled, config.py:390).
+    nms_fn(dets (k,5) f32, thresh) -> kept indices ascending; default = the C oracle's greedy NMS
+    (cython_nms.pyx:37-87 semantics)."""
+    if nms_fn is None:
+        from . import c_oracle
+        nms_fn = lambda d, t: c_oracle.nms(np.ascontiguousarray(d[:, :4]), np.ascontiguousarray(d[:, 4]), t, 0)
+    cls_boxes = [[] for _ in range(num_classes)]
+    im_inds = []
+    for j in range(1, num_classes):
+        inds = np.where(scores[:, j] > score_thresh)[0]
+        scores_j = scores[inds, j]
+        boxes_j = boxes[inds, j * 4:(j + 1) * 4]
+        dets_j = np.hstack((boxes_j, scores_j[:, np.newaxis])).astype(np.float32, copy=False)
+        keep = np.asarray(nms_fn(dets_j, nms_thresh), np.int64) if dets_j.shape[0] else np.zeros((0,), np.int64)
+        nms_dets = dets_j[keep, :]
+        im_inds.append(inds[keep])
+        label_j = np.ones((nms_dets.shape[0], 1), dtype=np.float32) * j
+        cls_boxes[j] = np.hstack((nms_dets, label_j))
+    if detections_per_im > 0:
+        image_scores = np.hstack([cls_boxes[j][:, -2] for j in range(1, num_classes)])
+        if len(image_scores) > detections_per_im:
+            image_thresh = np.sort(image_scores)[-detections_per_im]
+            for j in range(1, num_classes):
+                keep = np.where(cls_boxes[j][:, -2] >= image_thresh)[0]
+                im_inds[j - 1] = im_inds[j - 1][keep]
+                cls_boxes[j] = cls_boxes[j][keep, :]
+    im_results = np.vstack([cls_boxes[j] for j in range(1, num_classes)])
+    return im_results[:, -2], im_results[:, :-2], im_results[:, -1], np.concatenate(im_inds, 0)
+
+
+def prepare_det_rois(rois, scores, box_deltas, im_info, batch_size=1, score_thresh=0.05, nms_thresh=0.5,
+                     detections_per_im=100, reg_weights=(10., 10., 5., 5.)):
+    """model_builder_rel.py:1212-1259 + get_det_boxes :1261-1278 (TEST.BBOX_REG, class-specific deltas)."""
+    det_rois = np.empty((0, 5), dtype=np.float32)
+    det_labels = np.empty((0), dtype=np.float32)
+    det_scores = np.empty((0), dtype=np.float32)
+    det_inds_mapping = np.empty((0), dtype=np.int32)
+    for im_i in range(batch_size):
+        inds = np.where(abs(rois[:, 0] - im_i) < 1e-06)[0]
+        im_boxes = rois[inds, 1:5] / im_info[im_i, 2]
+        im_scores = scores[inds].reshape([-1, scores.shape[-1]])
+        im_box_deltas = box_deltas[inds].reshape([-1, box_deltas.shape[-1]])
+        pred = bbox_transform(im_boxes, im_box_deltas, reg_weights)
+        pred = clip_tiled_boxes(pred, im_info[im_i][:2] / im_info[im_i][2])
+        s, b, l, ii = box_results_with_nms_and_limit(im_scores, pred, im_scores.shape[1], score_thresh, nms_thresh,
+                                                     detections_per_im)
+        batch_inds = im_i * np.ones((b.shape[0], 1), dtype=np.float32)
+        det_rois = np.append(det_rois, np.hstack((batch_inds, b * im_info[im_i, 2])), axis=0)
+        det_labels = np.append(det_labels, l, axis=0)
+        det_scores = np.append(det_scores, s, axis=0)
+        det_inds_mapping = np.append(det_inds_mapping, inds[ii], axis=0)
+    return det_rois, det_labels, det_scores, det_inds_mapping

@@ -151,3 +151,18 @@ def test_pair_attention_and_sem_match_reference(golden):
     sem = head_ref.sem_feat(sd, torch.from_numpy(g["softmax_obj_vec"]), torch.from_numpy(g["region_feature"]), lca,
                             g["X"], g["Y"])
     close(sem, g["out_sem"])
+
+
+def test_det_branch_matches_reference(golden):
+    """prepare_det_rois / get_det_boxes / box_results_with_nms_and_limit (model_builder_rel.py:1212-1340)."""
+    g = golden("py_det_branch.npz")
+    c = jload(g["cfg"])
+    for key in jload(g["cases"]):
+        dr, dl, ds, di = np_oracle.prepare_det_rois(g[key + "_rois"], g[key + "_cls_scores"], g[key + "_bbox_pred"],
+                                                    g[key + "_im_info"], 1, c["score_thresh"], c["nms"],
+                                                    c["detections_per_im"], tuple(c["reg_weights"]))
+        assert np.array_equal(di, g[key + "_out_inds"]), key
+        assert np.array_equal(dl, g[key + "_out_det_labels"]), key
+        assert np.array_equal(ds, g[key + "_out_det_scores"]), key
+        assert np.array_equal(dr, g[key + "_out_det_rois"]), key
+    assert g["r300_out_inds"].shape[0] == 100            # the DETECTIONS_PER_IM cap was exercised

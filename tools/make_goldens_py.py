@@ -15,6 +15,7 @@ What is pinned (each checked against the oracle restatement in tests/test_oracle
   py_cluster_tree3d.npz  combine_tree/cluster_tree3d.py:114-366 whole forward (temporal ROIAlign, attention,
                          region tree, tree-GRU x groups, FFN) at reduced widths
   py_pair_head.npz       model_builder_rel.py:1524-1612 get_spatio_atten_feat, :1643-1668 get_sem_feat
+  py_det_branch.npz      model_builder_rel.py:1212-1340 prepare_det_rois / get_det_boxes / box_results_with_nms_and_limit
 """
 import json
 import os
@@ -289,6 +290,51 @@ def main():
              out_s_map=s_map.numpy(), out_o_map=o_map.numpy(), out_v_map=v_map.numpy(),
              out_lca=np.asarray(lca_list[0]).astype(np.int64), out_sem=sem.numpy())
     np.savez_compressed(os.path.join(OUT, "py_pair_head.npz"), **p)
+    # ------------------------------------------------------------------ detected-box branch
+    # prepare_det_rois -> get_det_boxes -> box_results_with_nms_and_limit (model_builder_rel.py:1212-1340), the
+    # reference's Python as is.  Its NMS call (utils/boxes.py:324-328 -> cython_nms, not buildable here) is served
+    # by the reference's own compiled csrc/cpu/nms_cpu.cpp - the same greedy algorithm (">=", "+1" areas,
+    # ascending-index result); scores are distinct, so the two orderings (argsort()[::-1] / sort(descending)) agree.
+    ref_c = sys.modules["model._C"]
+
+    def nms_via_ref_cpu(dets, thresh):
+        if dets.shape[0] == 0:
+            return []
+        return ref_c.nms(torch.from_numpy(np.ascontiguousarray(dets[:, :4])),
+                         torch.from_numpy(np.ascontiguousarray(dets[:, 4])), float(thresh)).numpy()
+    sys.modules["utils.cython_nms"].nms = nms_via_ref_cpu
+    cfg.TEST.NMS = 0.5
+    cfg.TEST.SCORE_THRESH = 0.05
+    cfg.TEST.DETECTIONS_PER_IM = 100
+    cfg.TEST.BBOX_REG = True
+    cfg.TEST.SOFT_NMS.ENABLED = False
+    cfg.TEST.BBOX_VOTE.ENABLED = False
+    cfg.MODEL.CLS_AGNOSTIC_BBOX_REG = False
+    cfg.ENABLE_FRAME_PRE_PROCESSING = False
+    d = {}
+    dn = types.SimpleNamespace()
+    for meth in ("get_det_boxes", "box_results_with_nms_and_limit"):
+        setattr(dn, meth, types.MethodType(getattr(Generalized_RCNN, meth), dn))
+    dcases = []
+    for name, R, ncls, sharp in (("r300", 300, 9, 3.0), ("r40", 40, 9, 1.0), ("r1", 1, 9, 4.0)):
+        cfg.MODEL.NUM_CLASSES = ncls
+        im_info = torch.tensor([[600.0, 800.0, 1.6]])
+        rb = synth_boxes(rng, R, 5.0, 790.0)
+        rb[:, 3] = np.minimum(rb[:, 3], 590.0)
+        rois_d = np.concatenate([np.zeros((R, 1), np.float32), rb], 1)
+        cls_scores = torch.softmax(torch.randn((R, ncls), generator=gen) * sharp, 1)
+        bbox_pred = torch.randn((R, 4 * ncls), generator=gen) * 0.5
+        dr, dl, dsc, dmap = Generalized_RCNN.prepare_det_rois(dn, rois_d, cls_scores, bbox_pred, im_info, "vidvrd_val",
+                                                              score_thresh=cfg.TEST.SCORE_THRESH, batch_size=1)
+        dcases.append(name)
+        d[name + "_rois"], d[name + "_cls_scores"], d[name + "_bbox_pred"] = rois_d, cls_scores.numpy(), bbox_pred.numpy()
+        d[name + "_im_info"] = im_info.numpy()
+        d[name + "_out_det_rois"], d[name + "_out_det_labels"] = dr, dl
+        d[name + "_out_det_scores"], d[name + "_out_inds"] = dsc, np.asarray(dmap).astype(np.int64)
+    d["cases"] = jbytes(dcases)
+    d["cfg"] = jbytes(dict(nms=0.5, score_thresh=0.05, detections_per_im=100, reg_weights=list(cfg.MODEL.BBOX_REG_WEIGHTS)))
+    np.savez_compressed(os.path.join(OUT, "py_det_branch.npz"), **d)
+
     for f in sorted(os.listdir(OUT)):
         print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))
 
