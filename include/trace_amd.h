@@ -236,6 +236,14 @@ int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int cols,
                          uint16_t* out, int ld_out, long long out_batch_stride,
                          trace_stream_t stream);
 
+/* Sub-sampled non-local block (mmcv NonLocal3d as configured by lib/i3d/
+ * i3d_nl_dot_product_r50_32x2x1_100e_kinetics400_rgb.py:15-19; call site lib/i3d/resnet3d.py:289):
+ * tpg (N,T,H,W,3c) bf16 = the theta|phi|g 1x1x1 convs run as one GEMM.  Max-pools (1,2,2) the phi and
+ * g thirds (the `sub_sample` MaxPool3d) and writes phi_p (N,nkp,c) and g^T (N,c,nkp), the operand
+ * layouts of the two products; nkp = T*(H/2)*(W/2) rounded up to 8, padding positions are zeros. */
+int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c,
+                             uint16_t* phi_p, uint16_t* gT, int nkp, trace_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* Context aggregation / relation head                                       */
 /* ------------------------------------------------------------------------ */
@@ -301,6 +309,23 @@ int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups,
                    float* h, float* hd,
                    float* workspace /* n_nodes*n_groups*Hd f32 */,
                    trace_stream_t stream);
+
+/* Top-k triplet ranking - lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 (+ argsort_desc,
+ * lib/datasets_rel/pytorch_misc.py:28-35), for every clip of a step at once, so that only topk records per
+ * clip leave the GPU.  prd (P_total, n_prd) f32 predicate scores; sbj/obj scores (P_total) f32 and labels
+ * (P_total) int64 of the pairs; pair_off (n_clips+1) int64 DEVICE array, clip b owns pairs
+ * [pair_off[b], pair_off[b+1]); max_pairs_per_clip is the host-known bound of a clip's pair count.
+ * Per pair the prd_k best predicates, score = sbj*obj*prd, per clip the topk best cells in descending score
+ * (ties: ascending (pair, slot) index = a stable descending sort).  Outputs (n_clips, topk): scores f32,
+ * clip-local pair index, predicate index, subject / object label (int64); rows of a clip with fewer than
+ * topk candidates are padded with score -1.  Limits: n_prd <= 256, max_pairs_per_clip*min(prd_k,n_prd) <= 16384
+ * (error otherwise).  workspace: trace_rank_triplets_workspace_bytes(P_total, min(prd_k,n_prd)) bytes, 256-aligned. */
+size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k);
+int trace_rank_triplets(const float* prd, int P_total, int n_prd, const float* sbj_scores,
+                        const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
+                        const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,
+                        float* top_scores, int64_t* top_pair, int64_t* top_prd, int64_t* top_sbj,
+                        int64_t* top_obj, void* workspace, size_t workspace_bytes, trace_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -121,3 +121,70 @@ def test_pair_attention_fused_vs_unfused():
         assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
     gv = v_map.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
     assert float((gv - vp).abs().max()) <= 1e-2 * float(vp.abs().max())
+
+
+@pytest.mark.parametrize("prd_k,topk", [(1, 100), (3, 100), (20, 50), (200, 7)])
+def test_rank_triplets_vs_oracle(prd_k, topk):
+    """task_evaluation_vg_and_vrd.py:207-228 per clip (ragged clips, one with fewer candidates than topk)."""
+    from trace_amd import ops
+    from oracle import np_oracle
+    rng = np.random.default_rng(prd_k)
+    n_prd = 132
+    pairs = [380, 2, 90, 0, 1, 600] if prd_k <= 20 else [120, 2, 90, 0, 1, 60]   # <= 16384 candidates per clip
+    poff = np.concatenate([[0], np.cumsum(pairs)]).astype(np.int64)
+    P = int(poff[-1])
+    prd = rng.random((P, n_prd)).astype(np.float32)
+    prd[5, :] = 0.5                                   # ties inside a pair: lowest predicate index first
+    ss, os_ = rng.random(P).astype(np.float32), rng.random(P).astype(np.float32)
+    sl, ol = rng.integers(1, 36, P), rng.integers(1, 36, P)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = ops.rank_triplets(t(prd), t(ss), t(os_), t(sl), t(ol), t(poff), max(pairs), topk, prd_k)
+    kk = min(prd_k, n_prd)
+    for b, nb in enumerate(pairs):
+        sl_ = slice(int(poff[b]), int(poff[b + 1]))
+        k = min(topk, nb * kk)
+        got_s = out["top_scores"][b].cpu().numpy()
+        assert (got_s[k:] == -1).all()
+        if nb == 0:
+            continue
+        # oracle with the same tie rule (stable descending order over (pair, slot))
+        lab = np.argsort(-prd[sl_], axis=1, kind="stable")[:, :kk]
+        sc = np.take_along_axis(prd[sl_], lab, 1)
+        spo = ((ss[sl_] * os_[sl_])[:, None] * sc).astype(np.float32)
+        order = np.argsort(-spo.ravel(), kind="stable")[:k]
+        assert np.array_equal(got_s[:k], spo.ravel()[order])
+        assert np.array_equal(out["top_pair"][b, :k].cpu().numpy(), order // kk)
+        assert np.array_equal(out["top_prd"][b, :k].cpu().numpy(), lab.ravel()[order])
+        assert np.array_equal(out["top_sbj"][b, :k].cpu().numpy(), sl[sl_][order // kk])
+        assert np.array_equal(out["top_obj"][b, :k].cpu().numpy(), ol[sl_][order // kk])
+        if prd_k == 1:   # same cells as the restated reference ranking (distinct scores)
+            s_ref, pair_ref, prd_ref = np_oracle.topk_triplets(prd[sl_], ss[sl_], os_[sl_], 1, k)
+            assert np.array_equal(pair_ref, order // kk) and np.array_equal(prd_ref, lab.ravel()[order])
+
+
+def test_rank_triplets_rejects_oversize():
+    from trace_amd import ops
+    P = 600
+    z = torch.zeros((P,), device=DEV)
+    lab = torch.ones((P,), dtype=torch.int64, device=DEV)
+    poff = torch.tensor([0, P], dtype=torch.int64, device=DEV)
+    assert not ops.rank_triplets_supported(132, P, 132)
+    with pytest.raises(RuntimeError, match="candidates"):
+        ops.rank_triplets(torch.zeros((P, 132), device=DEV), z, z, lab, lab, poff, P, 10, 132)
+
+
+@pytest.mark.parametrize("T,H,W,c", [(4, 28, 28, 256), (4, 14, 14, 512), (2, 6, 10, 64)])
+def test_nl_pool_split_vs_torch(T, H, W, c):
+    """Fused (1,2,2) max-pool + operand layouts of the sub-sampled non-local block (resnet3d.py:289)."""
+    from trace_amd import ops
+    g = torch.Generator().manual_seed(T * H)
+    N = 3
+    tpg = torch.randn((N, T, H, W, 3 * c), generator=g).to(DEV).bfloat16()
+    phi_p, gT, nkv = ops.nl_pool_split(tpg, c)
+    x = tpg.float().permute(0, 4, 1, 2, 3)                       # (N, 3c, T, H, W)
+    pooled = torch.nn.functional.max_pool3d(x[:, c:], (1, 2, 2))  # phi | g
+    assert nkv == T * (H // 2) * (W // 2)
+    ref_phi = pooled[:, :c].reshape(N, c, nkv).permute(0, 2, 1)
+    ref_g = pooled[:, c:].reshape(N, c, nkv)
+    assert torch.equal(phi_p[:, :nkv].float(), ref_phi) and torch.equal(gT[:, :, :nkv].float(), ref_g)
+    assert (phi_p[:, nkv:] == 0).all() and (gT[:, :, nkv:] == 0).all()

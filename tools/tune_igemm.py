@@ -21,18 +21,30 @@ QUICK = "--quick" in sys.argv
 dev = "cuda:0"
 
 
-def bench(fn, n=15):
-    for _ in range(2):
+def bench(fn, n=20, reps=3):
+    """GPU time per launch: n launches captured into a HIP graph and replayed (no host launch cost in
+    the measurement, as in the product's captured step)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True)
-    e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n):
-        fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e3  # us
+    best = 1e30
+    for _ in range(reps):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        best = min(best, s.elapsed_time(e) / n * 1e3)
+    return best  # us
 
 
 CONVS = [
@@ -81,13 +93,13 @@ def sweep(run, batch, name, M, N, K, cnt, flops):
     lib.trace_igemm_tune(0, 0, 0)
     t_def = bench(run)
     best = (t_def, (0, 0, 0))
-    tiles = (1, 2, 3, 4) if N > 64 else (1, 2)
+    tiles = (1, 2, 3, 4, 5, 6, 7) if N > 128 else ((1, 2, 3, 4, 5) if N > 64 else (1, 2))
     ksp = (1, 2, 4, 8) if batch == 1 and K >= 512 else (1,)
     if M <= 1024 and K >= 8192:
-        ksp = (0,)
+        ksp = (0, 4, 8, 16)
     nsts = (2, 3) if QUICK else (2, 3, 4)
     for tile, nst, ks in itertools.product(tiles, nsts, ksp):
-        lds = {1: 128, 2: 192, 3: 192, 4: 256}[tile] * 128 * nst
+        lds = {1: 128, 2: 192, 3: 192, 4: 256, 5: 384, 6: 384, 7: 512}[tile] * 128 * nst
         if lds > 160 * 1024:
             continue
         lib.trace_igemm_tune(tile, nst, ks)

@@ -34,6 +34,9 @@ SIGNATURES = {
     "trace_roi_pool_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "trace_roi_align_fwd_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "trace_nl_pool_split_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "trace_rank_triplets_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "trace_rank_triplets": (c_int, [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "trace_nms_grouped": (c_int, [P, P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),

@@ -543,6 +543,127 @@ __global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, i
     hdg[(vb + idx / Hd) * ldh + idx % Hd] = hdl[idx];
 }
 
+
+// ---------------------------------------------------------------------------
+// Triplet ranking: lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 on device.
+//   per pair: the prd_k best predicates (:207-208), score = sbj * obj * prd (:214-215)
+//   per clip: the topk best (pair, predicate) cells (:227 argsort_desc()[:topk])
+// Order everywhere: descending score, ties by ascending index (the order of a stable descending sort).
+// ---------------------------------------------------------------------------
+constexpr int RANK_MAX_PRD = 256;      // predicates per pair held in registers (4 per lane)
+constexpr int RANK_MAX_CAND = 16384;   // candidates per clip sorted in LDS (128 KiB)
+
+__device__ __forceinline__ bool rank_before(float sa, int ia, float sb, int ib) {
+  return (sa > sb) || (sa == sb && ia < ib);
+}
+
+// One wave per pair: kk rounds of wave-wide arg-max over the pair's predicate scores.
+__global__ __launch_bounds__(256) void rank_pair_topk_kernel(const float* __restrict__ prd, int n_prd,
+                                                             const float* __restrict__ sbj_sc,
+                                                             const float* __restrict__ obj_sc, int P, int kk,
+                                                             float* __restrict__ cand_score,
+                                                             int32_t* __restrict__ cand_prd) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = lane + 64 * j;
+    v[j] = i < n_prd ? prd[(long long)p * n_prd + i] : -__builtin_inff();
+  }
+  const float so = sbj_sc[p] * obj_sc[p];  // :214
+  for (int slot = 0; slot < kk; ++slot) {
+    float bv = v[0];
+    int bi = lane;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (rank_before(v[j], lane + 64 * j, bv, bi)) {
+        bv = v[j];
+        bi = lane + 64 * j;
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off);
+      const int oi = __shfl_xor(bi, off);
+      if (rank_before(ov, oi, bv, bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (bi == lane + 64 * j) v[j] = -__builtin_inff();  // taken
+    if (lane == 0) {
+      cand_score[(long long)p * kk + slot] = so * bv;  // :215
+      cand_prd[(long long)p * kk + slot] = bi;
+    }
+  }
+}
+
+// One workgroup per clip: bitonic sort of the clip's P_b*kk candidates in LDS, first topk written out.
+__global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __restrict__ cand_score,
+                                                              const int32_t* __restrict__ cand_prd,
+                                                              const int64_t* __restrict__ poff, int kk,
+                                                              const int64_t* __restrict__ sbj_lab,
+                                                              const int64_t* __restrict__ obj_lab, int topk,
+                                                              int npow2, float* __restrict__ top_scores,
+                                                              int64_t* __restrict__ top_pair,
+                                                              int64_t* __restrict__ top_prd,
+                                                              int64_t* __restrict__ top_sbj,
+                                                              int64_t* __restrict__ top_obj) {
+  extern __shared__ __attribute__((aligned(16))) char rank_smem[];
+  float* key = (float*)rank_smem;
+  int* idx = (int*)(rank_smem + (size_t)npow2 * sizeof(float));
+  const int b = blockIdx.x;
+  const long long p0 = poff[b], p1 = poff[b + 1];
+  const int n = (int)(p1 - p0) * kk;
+  const float* cs = cand_score + p0 * kk;
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    key[i] = i < n ? cs[i] : -__builtin_inff();
+    idx[i] = i < n ? i : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float si = key[i], sj = key[ixj];
+          const int ii = idx[i], ij = idx[ixj];
+          const bool up = ((i & k) == 0);
+          const bool swap = up ? rank_before(sj, ij, si, ii) : rank_before(si, ii, sj, ij);
+          if (swap) {
+            key[i] = sj;
+            key[ixj] = si;
+            idx[i] = ij;
+            idx[ixj] = ii;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    const long long o = (long long)b * topk + j;
+    if (j < n) {
+      const int c = idx[j];
+      const long long pair = c / kk;
+      top_scores[o] = key[j];
+      top_pair[o] = pair;
+      top_prd[o] = cand_prd[p0 * kk + c];
+      top_sbj[o] = sbj_lab[p0 + pair];
+      top_obj[o] = obj_lab[p0 + pair];
+    } else {  // fewer candidates than topk: padding the caller slices off
+      top_scores[o] = -1.0f;
+      top_pair[o] = 0;
+      top_prd[o] = 0;
+      top_sbj[o] = 0;
+      top_obj[o] = 0;
+    }
+  }
+}
+
 }  // namespace trace
 
 using namespace trace;
@@ -656,4 +777,50 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
     hipLaunchKernelGGL(tree_gru_kernel<false>, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
   }
   return check_launch("tree_gru");
+}
+
+extern "C" size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k) {
+  if (P_total < 0 || prd_k < 0) return 0;
+  return (size_t)P_total * prd_k * 8 + 256;
+}
+
+extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, const float* sbj_scores,
+                                   const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
+                                   const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,
+                                   float* top_scores, int64_t* top_pair, int64_t* top_prd, int64_t* top_sbj,
+                                   int64_t* top_obj, void* workspace, size_t workspace_bytes, trace_stream_t stream) {
+  TRACE_REQUIRE(P_total >= 0 && n_prd > 0 && n_clips >= 0 && prd_k > 0 && topk > 0 && max_pairs_per_clip >= 0,
+                "rank_triplets: bad shape");
+  TRACE_REQUIRE(n_prd <= RANK_MAX_PRD, "rank_triplets: %d predicate classes exceed the supported %d", n_prd, RANK_MAX_PRD);
+  const int kk = prd_k < n_prd ? prd_k : n_prd;
+  TRACE_REQUIRE((long long)max_pairs_per_clip * kk <= RANK_MAX_CAND,
+                "rank_triplets: %d pairs x %d predicates per clip exceed the %d candidates sorted on chip",
+                max_pairs_per_clip, kk, RANK_MAX_CAND);
+  if (n_clips == 0) return 0;
+  TRACE_REQUIRE(pair_off && top_scores && top_pair && top_prd && top_sbj && top_obj, "rank_triplets: null pointer");
+  TRACE_REQUIRE(P_total == 0 || (prd && sbj_scores && obj_scores && sbj_labels && obj_labels && workspace),
+                "rank_triplets: null pointer");
+  TRACE_REQUIRE(workspace_bytes >= trace_rank_triplets_workspace_bytes(P_total, kk), "rank_triplets: workspace too small");
+  TRACE_REQUIRE(((uintptr_t)workspace & 255) == 0, "rank_triplets: workspace must be 256-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  float* cand_score = (float*)workspace;
+  int32_t* cand_prd = (int32_t*)((char*)workspace + (((size_t)P_total * kk * 4 + 255) & ~(size_t)255));
+  if (P_total > 0)
+    hipLaunchKernelGGL(rank_pair_topk_kernel, dim3(ceil_div(P_total, 4)), dim3(256), 0, s, prd, n_prd, sbj_scores,
+                       obj_scores, P_total, kk, cand_score, cand_prd);
+  int npow2 = 64;
+  while (npow2 < max_pairs_per_clip * kk) npow2 <<= 1;
+  const size_t lds = (size_t)npow2 * 8;
+  if (lds > 64 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_clip_topk_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, RANK_MAX_CAND * 8);
+      TRACE_REQUIRE(e == hipSuccess, "rank_triplets: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL(rank_clip_topk_kernel, dim3(n_clips), dim3(1024), lds, s, cand_score, cand_prd, pair_off, kk,
+                     sbj_labels, obj_labels, topk, npow2, top_scores, top_pair, top_prd, top_sbj, top_obj);
+  return check_launch("rank_triplets");
 }

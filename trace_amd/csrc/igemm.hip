@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
 
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
-  int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128
+  int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256
   int nst;     // 2..4
   int ksplit;  // >= 1
 };
@@ -741,9 +741,11 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     const long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
     if (ksplit_req > 0) {
       ks = ksplit_req;
-    } else if (nblk < 256 && ksteps >= 8) {
-      ks = (768 + nblk - 1) / nblk;
-      if (ks > ksteps / 4) ks = ksteps / 4;
+    } else if (nblk < 256 && ksteps >= 32) {
+      // measured (tools/tune_igemm.py): slices only pay for deep K; aim at ~2 workgroups per CU and keep
+      // >= 16 K-steps per slice (the f32 slabs and the reduce launch cost more than shallow slices return)
+      ks = (512 + nblk - 1) / nblk;
+      if (ks > ksteps / 16) ks = ksteps / 16;
     }
     if (ks > ksteps) ks = ksteps;
     if (ks > cap_ws) ks = cap_ws;
@@ -760,6 +762,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
   if (nst < 2) nst = 2;
   if (nst > 4) nst = 4;
   const size_t stage = (size_t)(TC + TP) * 128;
+  while (nst > 2 && nst * stage > 160 * 1024) --nst;  // 160 KiB of LDS per CU
   if (use_v1) {
     hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), grid, dim3(256), 2 * stage, s, p);
   } else {
@@ -799,8 +802,8 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
     auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
     if (p.Cout <= 64) tile = 2;                                                   // 64 couts x 128 positions
-    else if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) tile = 3;        // weight streaming + split-K
-    else if (blocks(128, 128) >= 512) tile = 4;
+    else if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) tile = 4;        // weight streaming + split-K
+    else if (blocks(128, 128) >= 384) tile = 4;
     else if (blocks(128, 64) >= 384) tile = 3;
     else tile = 1;                                                                // 64 x 64: small problems
   }
@@ -808,6 +811,9 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     case 1: return launch_cfg<2, 2>(p, batch, s, t.nst, t.ksplit);
     case 2: return launch_cfg<2, 4>(p, batch, s, t.nst, t.ksplit);
     case 3: return launch_cfg<4, 2>(p, batch, s, t.nst, t.ksplit);
+    case 5: return launch_cfg<4, 8>(p, batch, s, t.nst, t.ksplit);
+    case 6: return launch_cfg<8, 4>(p, batch, s, t.nst, t.ksplit);
+    case 7: return launch_cfg<8, 8>(p, batch, s, t.nst, t.ksplit);
     default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
   }
 }
@@ -817,7 +823,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
 using namespace trace;
 
 extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
-  TRACE_REQUIRE(tile >= 0 && tile <= 4 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
+  TRACE_REQUIRE(tile >= 0 && tile <= 7 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
   g_tune = IgemmTune{tile, nst, ksplit};
   return 0;
 }

@@ -103,6 +103,71 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
   }
 }
 
+
+// Non-local block, sub-sampled (mmcv NonLocal3d, call site lib/i3d/resnet3d.py:289; cfg
+// i3d_nl_dot_product_...py:15-19): the theta|phi|g 1x1x1 convs run as ONE GEMM whose output rows are
+// [theta | phi | g] (3c channels).  This kernel max-pools (1,2,2) the phi and g thirds and writes them in
+// the layouts the two products read: phi_p (N, nkp, c) row-major (B operand of theta.phi^T) and g^T
+// (N, c, nkp) (B operand of pairwise.g), key positions nkv..nkp-1 zero-filled (nkp = nkv rounded up to 8).
+// Block = 64 key positions x 64 channels; g goes through an LDS tile for the transposed 16-byte stores.
+__global__ __launch_bounds__(256) void nl_pool_split_kernel(const uint16_t* __restrict__ tpg, int T, int H, int W,
+                                                            int c, int nkv, int nkp,
+                                                            uint16_t* __restrict__ phi_p,
+                                                            uint16_t* __restrict__ gT) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64][72];
+  const int n = blockIdx.z;
+  const int p0 = blockIdx.x * 64, ch0 = blockIdx.y * 64;
+  const int Ho = H >> 1, Wo = W >> 1, C3 = 3 * c;
+  const uint16_t* src = tpg + (long long)n * T * H * W * C3;
+  for (int item = threadIdx.x; item < 512; item += 256) {
+    const int pl = item >> 3, g8 = item & 7;
+    const int p = p0 + pl;
+    float mphi[8], mg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mphi[j] = mg[j] = 0.f;
+    if (p < nkv) {
+      const int wo = p % Wo, r = p / Wo, ho = r % Ho, t = r / Ho;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mphi[j] = mg[j] = -__builtin_inff();
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const uint16_t* px = src + (((long long)t * H + 2 * ho + dy) * W + 2 * wo + dx) * C3 + ch0 + g8 * 8;
+          const uint4 a = *reinterpret_cast<const uint4*>(px + c);
+          const uint4 b = *reinterpret_cast<const uint4*>(px + 2 * c);
+          const uint32_t* ua = &a.x;
+          const uint32_t* ub = &b.x;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            mphi[2 * j] = fmaxf(mphi[2 * j], __uint_as_float(ua[j] << 16));
+            mphi[2 * j + 1] = fmaxf(mphi[2 * j + 1], __uint_as_float(ua[j] & 0xffff0000u));
+            mg[2 * j] = fmaxf(mg[2 * j], __uint_as_float(ub[j] << 16));
+            mg[2 * j + 1] = fmaxf(mg[2 * j + 1], __uint_as_float(ub[j] & 0xffff0000u));
+          }
+        }
+    }
+    if (p < nkp) {
+      uint4 o;
+      o.x = pack_bf16x2(mphi[0], mphi[1]);
+      o.y = pack_bf16x2(mphi[2], mphi[3]);
+      o.z = pack_bf16x2(mphi[4], mphi[5]);
+      o.w = pack_bf16x2(mphi[6], mphi[7]);
+      *reinterpret_cast<uint4*>(phi_p + ((long long)n * nkp + p) * c + ch0 + g8 * 8) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[g8 * 8 + j][pl] = f32_to_bf16(mg[j]);
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < 512; item += 256) {
+    const int ch = item >> 3, pg = item & 7;
+    const int p = p0 + pg * 8;
+    if (p < nkp)  // nkp % 8 == 0: a group of 8 key positions is inside or outside as a whole
+      *reinterpret_cast<uint4*>(gT + ((long long)n * c + ch0 + ch) * nkp + p) =
+          *reinterpret_cast<const uint4*>(&tile[ch][pg * 8]);
+  }
+}
+
 }  // namespace trace
 
 using namespace trace;
@@ -152,4 +217,19 @@ extern "C" int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64), batch),
                      dim3(256), 0, (hipStream_t)stream, in, rows, cols, out, ld_out, out_batch_stride);
   return check_launch("transpose_bf16");
+}
+
+extern "C" int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c, uint16_t* phi_p,
+                                        uint16_t* gT, int nkp, trace_stream_t stream) {
+  TRACE_REQUIRE(N >= 0 && T > 0 && H >= 2 && W >= 2 && c > 0, "nl_pool_split: bad shape");
+  TRACE_REQUIRE(c % 64 == 0, "nl_pool_split: inter channels %d must be a multiple of 64", c);
+  const int nkv = T * (H / 2) * (W / 2);
+  TRACE_REQUIRE(nkp >= nkv && nkp % 8 == 0 && nkp < nkv + 8, "nl_pool_split: nkp must be nkv rounded up to 8");
+  if (N == 0) return 0;
+  TRACE_REQUIRE(N <= 65535, "nl_pool_split: batch too large");
+  TRACE_REQUIRE(tpg && phi_p && gT, "nl_pool_split: null pointer");
+  TRACE_REQUIRE((((uintptr_t)tpg | (uintptr_t)phi_p | (uintptr_t)gT) & 15) == 0, "nl_pool_split: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(nl_pool_split_kernel, dim3(ceil_div(nkp, 64), c / 64, N), dim3(256), 0, (hipStream_t)stream, tpg,
+                     T, H, W, c, nkv, nkp, phi_p, gT);
+  return check_launch("nl_pool_split_bf16");
 }

@@ -387,7 +387,7 @@ class Generalized_RCNN(nn.Module):
                   t_obj=upl.add(np.concatenate(t_obj, 0)), t_reg=upl.add(np.concatenate(t_reg, 0)),
                   reg=upl.add(np.concatenate(reg_rois, 0)),
                   pclip=upl.add(np.repeat(np.arange(B), np.diff(poff)).astype(np.int64)),
-                  poff=upl.add(poff[:-1].astype(np.int64)))
+                  poff=upl.add(poff.astype(np.int64)))
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
                     sig=(Tn, tuple(n_list), tuple(m_list)),
@@ -525,8 +525,13 @@ class Generalized_RCNN(nn.Module):
         # ---- gathers and the ranking run once over all clips (:1162-1182 values)
         top = None
         if topk:
-            top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
-                                             dv[ix["pclip"]], poff, dv[ix["poff"]], topk, prd_k)
+            pmax = int(np.max(np.diff(poff))) if len(poff) > 1 else 0
+            if ops.rank_triplets_supported(prd.shape[1], pmax, prd_k):
+                top = ops.rank_triplets(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all, dv[ix["poff"]], pmax,
+                                        min(topk, max(pmax * min(prd_k, prd.shape[1]), 1)), prd_k)
+            else:   # more candidates per clip than the on-chip sort holds: torch's top-k on the GPU
+                top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
+                                                 dv[ix["pclip"]], poff, dv[ix["poff"]][:-1], topk, prd_k)
         self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
                            q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
                            logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)

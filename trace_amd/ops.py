@@ -338,6 +338,23 @@ def transpose(x, pad_to=1):
     return out[0] if two_d else out
 
 
+def nl_pool_split(tpg, c):
+    """tpg (N,T,H,W,3c) bf16 (theta|phi|g) -> phi_p (N,nkp,c), g^T (N,c,nkp): (1,2,2) max-pool of the phi / g
+    thirds in the operand layouts of the non-local block's two products; nkp = nkv rounded up to 8."""
+    tpg = _bf16(tpg, "tpg")
+    N, T, H, W, C3 = tpg.shape
+    if C3 != 3 * c:
+        raise RuntimeError("nl_pool_split: last dim %d != 3*%d" % (C3, c))
+    nkv = T * (H // 2) * (W // 2)
+    nkp = (nkv + 7) // 8 * 8
+    phi_p = torch.empty((N, nkp, c), dtype=torch.bfloat16, device=tpg.device)
+    gT = torch.empty((N, c, nkp), dtype=torch.bfloat16, device=tpg.device)
+    with torch.cuda.device(tpg.device):
+        L.check(L.lib().trace_nl_pool_split_bf16(L.ptr(tpg), N, T, H, W, c, L.ptr(phi_p), L.ptr(gT), nkp, L.stream()),
+                "nl_pool_split")
+    return phi_p, gT, nkv
+
+
 def roi_align_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
     """x (B,H,W,C) bf16, rois (K,5) f32 -> (K, pooled, pooled, C) bf16."""
     x = _bf16(x, "x")
@@ -433,3 +450,36 @@ def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
                                        L.ptr(forest["child_idx"]), arr, int(max_tree_nodes), L.ptr(h), L.ptr(hd), L.ptr(ws),
                                        L.stream()), "tree_gru")
     return h, hd
+
+
+RANK_MAX_PRD = 256
+RANK_MAX_CAND = 16384
+
+
+def rank_triplets_supported(n_prd, max_pairs_per_clip, prd_k):
+    return n_prd <= RANK_MAX_PRD and max_pairs_per_clip * min(prd_k, n_prd) <= RANK_MAX_CAND
+
+
+def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off, max_pairs_per_clip, topk, prd_k=1):
+    """task_evaluation_vg_and_vrd.py:207-228 for every clip at once.  prd (P,n_prd) f32; scores (P) f32; labels
+    (P) int64; pair_off (B+1) int64 on the GPU.  Returns dict of (B, topk) tensors (rows padded with score -1)."""
+    prd, sbj_scores, obj_scores = _f32(prd), _f32(sbj_scores), _f32(obj_scores)
+    L.require_gpu(sbj_labels, obj_labels, pair_off)
+    if sbj_labels.dtype != torch.int64 or obj_labels.dtype != torch.int64 or pair_off.dtype != torch.int64:
+        raise RuntimeError("rank_triplets: labels and pair_off must be int64")
+    sbj_labels, obj_labels, pair_off = sbj_labels.contiguous(), obj_labels.contiguous(), pair_off.contiguous()
+    P, n_prd = prd.shape
+    B = pair_off.numel() - 1
+    dev = prd.device
+    kk = min(prd_k, n_prd)
+    lib = L.lib()
+    ws_bytes = lib.trace_rank_triplets_workspace_bytes(P, kk)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    top = torch.empty((B, topk), dtype=torch.float32, device=dev)
+    outs = [torch.empty((B, topk), dtype=torch.int64, device=dev) for _ in range(4)]
+    with torch.cuda.device(dev):
+        L.check(lib.trace_rank_triplets(L.ptr(prd), P, n_prd, L.ptr(sbj_scores), L.ptr(obj_scores), L.ptr(sbj_labels),
+                                        L.ptr(obj_labels), L.ptr(pair_off), B, int(max_pairs_per_clip), int(prd_k),
+                                        int(topk), L.ptr(top), L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]),
+                                        L.ptr(outs[3]), L.ptr(ws), ws_bytes, L.stream()), "rank_triplets")
+    return dict(top_scores=top, top_pair=outs[0], top_prd=outs[1], top_sbj=outs[2], top_obj=outs[3])

@@ -115,6 +115,7 @@ class NonLocal3d(nn.Module):
             self.phi = nn.Sequential(phi, nn.MaxPool3d(kernel_size=(1, 2, 2)))
         else:
             self.g, self.phi = g, phi
+        self._tpg = None
 
     def _conv(self, m):
         return m[0] if isinstance(m, nn.Sequential) else m
@@ -130,27 +131,44 @@ class NonLocal3d(nn.Module):
         y = torch.matmul(pw, g_x).permute(0, 2, 1).contiguous().reshape(n, c, *x.size()[2:])
         return x + self.conv_out(y)
 
+    def _tpg_packed(self):
+        """theta | phi | g stacked along the output channels: one GEMM instead of three."""
+        if self._tpg is None:
+            ws, bs = zip(*(m.packed() for m in (self.theta, self._conv(self.phi), self._conv(self.g))))
+            self._tpg = (torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous(), _PACK_EPOCH[0])
+        return self._tpg[:2]
+
     def run(self, x):
         N, T, H, W, C = x.shape
         c = self.inter_channels
-        theta = self.theta.run(x)
-        phi = self._conv(self.phi).run(x)
-        g = self._conv(self.g).run(x)
-        if self.sub_sample:
-            phi = ops.maxpool3d(phi, (1, 2, 2), (1, 2, 2))
-            g = ops.maxpool3d(g, (1, 2, 2), (1, 2, 2))
         nq = T * H * W
-        nkv = phi.shape[1] * phi.shape[2] * phi.shape[3]
-        # pairwise = theta^T phi / N_kv (dot_product: no softmax); y = pairwise g.  N_kv is padded
-        # to a multiple of 8 with zero columns (16-byte rows for the second product's operands).
-        nkp = (nkv + 7) // 8 * 8
-        phi = phi.view(N, nkv, c)
-        if nkp != nkv:  # odd map sizes only: zero key rows give zero pairwise columns
-            phi_p = torch.zeros((N, nkp, c), dtype=torch.bfloat16, device=x.device)
-            phi_p[:, :nkv] = phi
-            phi = phi_p
-        pw_full = ops.gemm_nt(theta.view(N, nq, c), phi, alpha=1.0 / nkv)
-        y = ops.gemm_nt(pw_full, ops.transpose(g.view(N, nkv, c), pad_to=8))
+        if self._tpg is not None and self._tpg[2] != _PACK_EPOCH[0]:
+            self._tpg = None
+        if self.sub_sample and c % 64 == 0:
+            # theta|phi|g in one launch, then ONE kernel pools phi / g and lays them out for the two products
+            w, b = self._tpg_packed()
+            tpg = ops.conv3d(x, w, b, (1, 1, 1))
+            phi, gT, nkv = ops.nl_pool_split(tpg, c)
+            theta = tpg.view(N, nq, 3 * c)[:, :, :c]
+        else:
+            theta = self.theta.run(x).view(N, nq, c)
+            phi = self._conv(self.phi).run(x)
+            g = self._conv(self.g).run(x)
+            if self.sub_sample:
+                phi = ops.maxpool3d(phi, (1, 2, 2), (1, 2, 2))
+                g = ops.maxpool3d(g, (1, 2, 2), (1, 2, 2))
+            nkv = phi.shape[1] * phi.shape[2] * phi.shape[3]
+            # N_kv is padded to a multiple of 8 with zero rows (16-byte rows for the second product's operands)
+            nkp = (nkv + 7) // 8 * 8
+            phi = phi.view(N, nkv, c)
+            if nkp != nkv:
+                phi_p = torch.zeros((N, nkp, c), dtype=torch.bfloat16, device=x.device)
+                phi_p[:, :nkv] = phi
+                phi = phi_p
+            gT = ops.transpose(g.view(N, nkv, c), pad_to=8)
+        # pairwise = theta^T phi / N_kv (dot_product: no softmax); y = pairwise g
+        pw_full = ops.gemm_nt(theta, phi, alpha=1.0 / nkv)
+        y = ops.gemm_nt(pw_full, gT)
         return self.conv_out.run(y.view(N, T, H, W, c), residual=x, relu=False)  # x + conv_out(y)
 
 
