@@ -169,6 +169,7 @@ int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
 #define TRACE_EPI_OUT_F32 4  /* write f32 instead of bf16                    */
 #define TRACE_EPI_LEAKY 8    /* LeakyReLU(0.1) instead of ReLU               */
 #define TRACE_EPI_RES_POST 16 /* add `residual` AFTER the activation          */
+#define TRACE_EPI_RES_F32 32 /* `residual` is f32, not bf16 (trace_gemm_bf16_nt_ex) */
 
 /* Conv3d + folded eval-mode BatchNorm3d (+residual)(+ReLU) as an implicit GEMM
  * on bf16 MFMA (mmcv ConvModule at resnet3d.py:250-283,549-557,721-730;
@@ -222,8 +223,22 @@ int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
                        void* workspace, size_t workspace_bytes,
                        trace_stream_t stream);
 
+/* trace_gemm_bf16_nt with the epilogue forms the relation head chains between its Linear layers
+ * (model_builder_rel.py:938-952, 1018-1024, 1039-1069; cluster_tree3d.py:192-201, 293-330), so that a
+ * sum or activation that the reference computes as a separate torch op costs no launch of its own:
+ *   residual      bf16, or f32 with TRACE_EPI_RES_F32 (e.g. det_feat = ori + Linear(...), :946)
+ *   strideBias    batch stride of `bias` (0 = shared)
+ *   C2, epilogue2 optional second output, same shape / ldc / strideC as C: bf16(act(C value)) with
+ *                 act = none | TRACE_EPI_RELU | TRACE_EPI_LEAKY - the operand of the next Linear when the
+ *                 f32 value itself is also needed (e.g. ori and relu(ori), :938-939).  NULL = none. */
+int trace_gemm_bf16_nt_ex(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda,
+                          int ldb, int ldc, int batch, long long strideA, long long strideB,
+                          long long strideC, float alpha, const float* bias, long long strideBias,
+                          const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
+                          void* workspace, size_t workspace_bytes, trace_stream_t stream);
+
 /* Launch-configuration override for the three entry points above, for the calling thread:
- * tile 1..4 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128), nst = LDS ring depth 2..4,
+ * tile 1..7 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128, 128 x 256, 256 x 128, 256x256), nst = LDS ring depth 2..4,
  * ksplit = split-K factor; 0 = let the library choose (the default).  No counterpart in the
  * reference (cuDNN picks its own algorithm there); used by tools/tune_igemm.py and the tests that
  * cover every tile shape. */
@@ -254,6 +269,11 @@ int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, in
 int trace_temporal_attention(const float* qs, const float* qo, const float* o,
                              int n, int T, int D, int K, float inv_sqrt_d,
                              float* out, trace_stream_t stream);
+/* Same, with an optional bf16 copy of the result (the operand of the value MLP's first Linear,
+ * cluster_tree3d.py:195); either output may be NULL. */
+int trace_temporal_attention_ex(const float* qs, const float* qo, const float* o, int n, int T, int D,
+                                int K, float inv_sqrt_d, float* out, uint16_t* out_bf16,
+                                trace_stream_t stream);
 
 /* Fused target-adaptive pair attention — lib/modeling_rel/
  * model_builder_rel.py:1524-1612 (get_spatio_atten_feat, get_rel_rois,
@@ -310,18 +330,40 @@ int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups,
                    float* workspace /* n_nodes*n_groups*Hd f32 */,
                    trace_stream_t stream);
 
+/* Glue of the relation head (csrc/glue_ops.hip): each replaces a chain of small torch ops of the reference
+ * by one launch.  `act` = 0 | TRACE_EPI_RELU | TRACE_EPI_LEAKY.
+ *   act_cast        out (rows, wa+wb) bf16 = act([a | b]) (b optional, wb = 0): F.relu / LeakyReLU(0.1) in front
+ *                   of a Linear (model_builder_rel.py:273,281-286,:939) and cat(h, hd) (cluster_tree.py:203)
+ *   layernorm_act   nn.LayerNorm + ReLU of the temporal value MLPs (cluster_tree3d.py:80-84, 91-95)
+ *   gather_add_act  out (rows,w) bf16 = act(a[r] + b[idx[r]]): low_s[X]+low_o[Y] + low_r[lca], LeakyReLU
+ *                   (model_builder_rel.py:1662, :326)
+ *   pair_assemble   per pair p = (X[p], Y[p]): labels / scores of subject and object (relpn_heads.py:113-116),
+ *                   so_bias = low_s[X]+low_o[Y] (P,wl), so_part = part_s[X]+part_o[Y] (+ freq[(ls-1)*n_obj+lo-1],
+ *                   sparse_targets_rel.py:67-72; freq may be NULL) (P,wp), model_builder_rel.py:1064-1075 */
+int trace_act_cast_bf16(const float* a, int wa, const float* b, int wb, long long rows, int act,
+                        uint16_t* out, trace_stream_t stream);
+int trace_layernorm_act_bf16(const float* x, int rows, int w, const float* gamma, const float* beta,
+                             float eps, int act, uint16_t* out, trace_stream_t stream);
+int trace_gather_add_act_bf16(const float* a, const float* b, const int64_t* idx, long long rows, int w,
+                              int act, uint16_t* out, trace_stream_t stream);
+int trace_pair_assemble(const int64_t* det_labels, const float* det_scores, const int64_t* X,
+                        const int64_t* Y, int P, const float* low_s, const float* low_o, int wl,
+                        const float* part_s, const float* part_o, int wp, const float* freq, int n_rel,
+                        int n_obj, int64_t* sbj_lab, int64_t* obj_lab, float* sbj_sc, float* obj_sc,
+                        float* so_bias, float* so_part, trace_stream_t stream);
+
 /* Top-k triplet ranking - lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 (+ argsort_desc,
  * lib/datasets_rel/pytorch_misc.py:28-35), for every clip of a step at once, so that only topk records per
  * clip leave the GPU.  prd (P_total, n_prd) f32 predicate scores; sbj/obj scores (P_total) f32 and labels
  * (P_total) int64 of the pairs; pair_off (n_clips+1) int64 DEVICE array, clip b owns pairs
  * [pair_off[b], pair_off[b+1]); max_pairs_per_clip is the host-known bound of a clip's pair count.
  * Per pair the prd_k best predicates, score = sbj*obj*prd, per clip the topk best cells in descending score
- * (ties: ascending (pair, slot) index = a stable descending sort).  Outputs (n_clips, topk): scores f32,
+ * (ties: ascending (pair, slot) index = a stable descending sort).  ld_prd = row stride of prd (>= n_prd).  Outputs (n_clips, topk): scores f32,
  * clip-local pair index, predicate index, subject / object label (int64); rows of a clip with fewer than
  * topk candidates are padded with score -1.  Limits: n_prd <= 256, max_pairs_per_clip*min(prd_k,n_prd) <= 16384
  * (error otherwise).  workspace: trace_rank_triplets_workspace_bytes(P_total, min(prd_k,n_prd)) bytes, 256-aligned. */
 size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k);
-int trace_rank_triplets(const float* prd, int P_total, int n_prd, const float* sbj_scores,
+int trace_rank_triplets(const float* prd, int P_total, int n_prd, int ld_prd, const float* sbj_scores,
                         const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
                         const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,
                         float* top_scores, int64_t* top_pair, int64_t* top_prd, int64_t* top_sbj,

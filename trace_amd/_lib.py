@@ -36,7 +36,12 @@ SIGNATURES = {
     "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_nl_pool_split_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "trace_rank_triplets_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "trace_rank_triplets": (c_int, [P, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "trace_rank_triplets": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "trace_act_cast_bf16": (c_int, [P, c_int, P, c_int, c_longlong, c_int, P, P]),
+    "trace_layernorm_act_bf16": (c_int, [P, c_int, c_int, P, P, c_float, c_int, P, P]),
+    "trace_gather_add_act_bf16": (c_int, [P, P, P, c_longlong, c_int, c_int, P, P]),
+    "trace_pair_assemble": (c_int, [P, P, P, P, c_int, P, P, c_int, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P, P]),
+    "trace_temporal_attention_ex": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "trace_nms_grouped": (c_int, [P, P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
@@ -49,6 +54,7 @@ SIGNATURES = {
     "trace_conv3d_stem_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 11 + [P, P]),
     "trace_conv3d_igemm_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 13 + [P, c_int, P, P, c_size_t, P]),
     "trace_maxpool3d_ndhwc_bf16": (c_int, [P] + [c_int] * 14 + [P, P]),
+    "trace_gemm_bf16_nt_ex": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, c_longlong, P, c_int, P, P, c_int, P, c_size_t, P]),
     "trace_gemm_bf16_nt": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, P, c_int, P, P, c_size_t, P]),
     "trace_igemm_tune": (c_int, [c_int, c_int, c_int]),
     "trace_transpose_bf16": (c_int, [P, c_int, c_int, c_int, P, c_int, c_longlong, P]),

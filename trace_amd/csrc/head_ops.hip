@@ -14,7 +14,7 @@ constexpr int TA_MAX_T = 128;
 
 __global__ __launch_bounds__(256) void temporal_attention_kernel(
     const float* __restrict__ qs, const float* __restrict__ qo, const float* __restrict__ o, int T,
-    int D, int K, float inv_sqrt_d, float* __restrict__ out) {
+    int D, int K, float inv_sqrt_d, float* __restrict__ out, uint16_t* __restrict__ out_bf16) {
   __shared__ float sc[TA_MAX_T];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     float acc = 0.f;
     for (int t = 0; t < T; ++t) acc += (expf(sc[t] - mx) * inv) * o[((long long)n * T + t) * K + k];
-    out[(long long)n * K + k] = acc;  // cluster_tree3d.py:349-350
+    if (out) out[(long long)n * K + k] = acc;  // cluster_tree3d.py:349-350
+    if (out_bf16) out_bf16[(long long)n * K + k] = f32_to_bf16(acc);
   }
 }
 
@@ -558,7 +559,7 @@ __device__ __forceinline__ bool rank_before(float sa, int ia, float sb, int ib) 
 }
 
 // One wave per pair: kk rounds of wave-wide arg-max over the pair's predicate scores.
-__global__ __launch_bounds__(256) void rank_pair_topk_kernel(const float* __restrict__ prd, int n_prd,
+__global__ __launch_bounds__(256) void rank_pair_topk_kernel(const float* __restrict__ prd, int n_prd, int ld_prd,
                                                              const float* __restrict__ sbj_sc,
                                                              const float* __restrict__ obj_sc, int P, int kk,
                                                              float* __restrict__ cand_score,
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(256) void rank_pair_topk_kernel(const float* __rest
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = lane + 64 * j;
-    v[j] = i < n_prd ? prd[(long long)p * n_prd + i] : -__builtin_inff();
+    v[j] = i < n_prd ? prd[(long long)p * ld_prd + i] : -__builtin_inff();
   }
   const float so = sbj_sc[p] * obj_sc[p];  // :214
   for (int slot = 0; slot < kk; ++slot) {
@@ -668,16 +669,23 @@ __global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __res
 
 using namespace trace;
 
-extern "C" int trace_temporal_attention(const float* qs, const float* qo, const float* o, int n, int T,
-                                        int D, int K, float inv_sqrt_d, float* out,
-                                        trace_stream_t stream) {
+extern "C" int trace_temporal_attention_ex(const float* qs, const float* qo, const float* o, int n, int T, int D,
+                                           int K, float inv_sqrt_d, float* out, uint16_t* out_bf16,
+                                           trace_stream_t stream) {
   TRACE_REQUIRE(n >= 0 && T > 0 && D > 0 && K > 0, "temporal_attention: bad shape");
   TRACE_REQUIRE(T <= TA_MAX_T, "temporal_attention: T=%d exceeds %d", T, TA_MAX_T);
   if (n == 0) return 0;
-  TRACE_REQUIRE(qs && qo && o && out, "temporal_attention: null pointer");
+  TRACE_REQUIRE(qs && qo && o && (out || out_bf16), "temporal_attention: null pointer");
   hipLaunchKernelGGL(temporal_attention_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, qs, qo, o,
-                     T, D, K, inv_sqrt_d, out);
+                     T, D, K, inv_sqrt_d, out, out_bf16);
   return check_launch("temporal_attention");
+}
+
+extern "C" int trace_temporal_attention(const float* qs, const float* qo, const float* o, int n, int T,
+                                        int D, int K, float inv_sqrt_d, float* out,
+                                        trace_stream_t stream) {
+  TRACE_REQUIRE(n == 0 || out, "temporal_attention: null pointer");
+  return trace_temporal_attention_ex(qs, qo, o, n, T, D, K, inv_sqrt_d, out, nullptr, stream);
 }
 
 extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap, int B, int H,
@@ -784,12 +792,13 @@ extern "C" size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k) {
   return (size_t)P_total * prd_k * 8 + 256;
 }
 
-extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, const float* sbj_scores,
+extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, int ld_prd, const float* sbj_scores,
                                    const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
                                    const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,
                                    float* top_scores, int64_t* top_pair, int64_t* top_prd, int64_t* top_sbj,
                                    int64_t* top_obj, void* workspace, size_t workspace_bytes, trace_stream_t stream) {
-  TRACE_REQUIRE(P_total >= 0 && n_prd > 0 && n_clips >= 0 && prd_k > 0 && topk > 0 && max_pairs_per_clip >= 0,
+  TRACE_REQUIRE(P_total >= 0 && n_prd > 0 && ld_prd >= n_prd && n_clips >= 0 && prd_k > 0 && topk > 0 &&
+                    max_pairs_per_clip >= 0,
                 "rank_triplets: bad shape");
   TRACE_REQUIRE(n_prd <= RANK_MAX_PRD, "rank_triplets: %d predicate classes exceed the supported %d", n_prd, RANK_MAX_PRD);
   const int kk = prd_k < n_prd ? prd_k : n_prd;
@@ -806,7 +815,7 @@ extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, con
   float* cand_score = (float*)workspace;
   int32_t* cand_prd = (int32_t*)((char*)workspace + (((size_t)P_total * kk * 4 + 255) & ~(size_t)255));
   if (P_total > 0)
-    hipLaunchKernelGGL(rank_pair_topk_kernel, dim3(ceil_div(P_total, 4)), dim3(256), 0, s, prd, n_prd, sbj_scores,
+    hipLaunchKernelGGL(rank_pair_topk_kernel, dim3(ceil_div(P_total, 4)), dim3(256), 0, s, prd, n_prd, ld_prd, sbj_scores,
                        obj_scores, P_total, kk, cand_score, cand_prd);
   int npow2 = 64;
   while (npow2 < max_pairs_per_clip * kk) npow2 <<= 1;

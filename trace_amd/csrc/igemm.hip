@@ -11,16 +11,16 @@
 //   * activations are channels-last bf16 (N,T,H,W,C): one output position's
 //     receptive-field tap is a contiguous C-vector, so the im2col matrix is
 //     never materialised - each K-step gathers 16-byte pieces straight from HBM/L2
-//     into registers (zero-filled at the padding halo) and stores them to LDS;
+//     into LDS by LDS-DMA (padding-halo pieces read a zero page);
 //   * weights are pre-packed (Cout, taps*C) bf16 with the BN scale folded in, the
 //     BN shift is the epilogue bias; residual add + ReLU are fused in the epilogue;
 //   * D = W_tile (A operand, rows = Cout) x X_tile^T (B operand, cols = output
 //     positions) on v_mfma_f32_16x16x32_bf16: a lane then owns 4 consecutive
-//     output channels of one position -> 8-byte channels-last stores;
+//     output channels of one position (8 after the row permutation below) -> 16-byte stores;
 //   * 4 waves / workgroup (2 x 2), wave tile (WM*16 couts) x (WN*16 positions),
-//     BK = 64, LDS double-buffered, XOR-swizzled 16-byte chunks (conflict-free
-//     ds_read_b128), next tile's global loads issued before the MFMA block
-//     (register-staged split pipeline), one barrier per K-step;
+//     BK = 64, NST-deep LDS ring, XOR-swizzled 16-byte chunks (conflict-free
+//     ds_read_b128), the next K-step's LDS-DMA loads in flight during the MFMA block,
+//     one barrier per K-step;
 //   * the same kernel runs plain/batched GEMMs (1 tap, explicit row strides).
 #include "common.h"
 #include <stdlib.h>
@@ -58,6 +58,9 @@ struct IgemmParams {
   int narrow;        // 1: Cout or ldo not a multiple of 8 -> 4-channel epilogue groups
   int dense;         // 1: rows of `in` are the GEMM rows (1 tap, unit stride, no padding)
   size_t ws_bytes;
+  uint16_t* out2;    // optional second output: bf16(act2(out value)), same rows / ldo as `out`
+  int epi2;          // TRACE_EPI_RELU | TRACE_EPI_LEAKY applied to the second output only
+  long long bs_bias; // blockIdx.z stride of `bias` (elements)
 };
 
 constexpr int BK = 64;
@@ -65,243 +68,6 @@ constexpr int BK = 64;
 // byte offset of 16-byte chunk `chunk` (0..7) of row `r` in a [rows][64] bf16 tile
 __device__ __forceinline__ int lds_off(int r, int chunk) {
   return r * 128 + ((chunk ^ (r & 7)) << 4);
-}
-
-template <int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmParams p) {
-  constexpr int TC = 32 * WM;  // cout rows per block
-  constexpr int TP = 32 * WN;  // positions per block
-  constexpr int A_BYTES = TC * 128;
-  constexpr int B_BYTES = TP * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [buf0: A | B][buf1: A | B]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD's L2; give each XCD a
-  // contiguous run of tiles so neighbouring position tiles reuse the same weights.
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  // default: cout tile fastest (a position tile's inputs stay hot in L2); weight-streaming shapes
-  // (few position tiles, huge K) flip it so the tiles sharing a weight panel run side by side.
-  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
-  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
-  const int cout0 = tile_n * TC;
-  const int pos0 = tile_m * TP;
-
-  const uint16_t* gin = p.in + (long long)blockIdx.z * p.bs_in;
-  const uint16_t* gw = p.w + (long long)blockIdx.z * p.bs_w;
-
-  // ---- per-thread load assignment: 16-byte piece `kseg` of rows (tid>>3)+32*i
-  const int kseg = tid & 7;
-  const int lrow = tid >> 3;
-  long long x_nbase[WN];
-  int x_t0[WN], x_h0[WN], x_w0[WN];
-#pragma unroll
-  for (int i = 0; i < WN; ++i) {
-    int m = pos0 + lrow + 32 * i;
-    if (m < p.M) {
-      int wo = m % p.Wo;
-      int t1 = m / p.Wo;
-      int ho = t1 % p.Ho;
-      int t2 = t1 / p.Ho;
-      int to = t2 % p.To;
-      int n = t2 / p.To;
-      x_nbase[i] = (long long)n * p.in_n_stride;
-      x_t0[i] = to * p.st - p.pt;
-      x_h0[i] = ho * p.sh - p.ph;
-      x_w0[i] = wo * p.sw - p.pw;
-    } else {
-      x_nbase[i] = 0;
-      x_t0[i] = -0x40000000;  // never in bounds
-      x_h0[i] = 0;
-      x_w0[i] = 0;
-    }
-  }
-  // K range of this block (split-K slices along blockIdx.y)
-  const int ksteps_all = (p.Ktot + BK - 1) / BK;
-  const int ks_begin = blockIdx.y * p.ks_per;
-  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
-  // running tap state of this thread's K piece
-  int klin = ks_begin * BK + kseg * 8;
-  int kc, ta, tb, tcw;
-  {
-    const int tap = klin / p.Crun;
-    kc = klin - tap * p.Crun;  // channel offset inside the current tap run
-    tcw = tap % p.kw;
-    const int t2 = tap / p.kw;
-    tb = t2 % p.kh;
-    ta = t2 / p.kh;
-  }
-
-  uint4 xr[WN], wr[WM];
-  auto load_tiles = [&]() {
-    const bool kvalid = ta < p.kt;
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      int ti = x_t0[i] + ta * p.dt, hi = x_h0[i] + tb * p.dh, wi = x_w0[i] + tcw * p.dw;
-      bool ok = kvalid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
-                (unsigned)wi < (unsigned)p.Wi;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        long long off = x_nbase[i] + ((long long)(ti * p.Hi + hi) * p.Wi + wi) * p.pix + kc;
-        v = *reinterpret_cast<const uint4*>(gin + off);
-      }
-      xr[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      int row = cout0 + lrow + 32 * i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kvalid && row < p.Cout) v = *reinterpret_cast<const uint4*>(gw + (long long)row * p.ldw + klin);
-      wr[i] = v;
-    }
-  };
-  auto advance_k = [&]() {
-    klin += BK;
-    kc += BK;
-    while (kc >= p.Crun) {
-      kc -= p.Crun;
-      if (++tcw == p.kw) {
-        tcw = 0;
-        if (++tb == p.kh) {
-          tb = 0;
-          ++ta;
-        }
-      }
-    }
-  };
-  auto store_tiles = [&](int buf) {
-    char* a = smem + buf * (A_BYTES + B_BYTES);
-    char* b = a + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) *reinterpret_cast<uint4*>(a + lds_off(lrow + 32 * i, kseg)) = wr[i];
-#pragma unroll
-    for (int i = 0; i < WN; ++i) *reinterpret_cast<uint4*>(b + lds_off(lrow + 32 * i, kseg)) = xr[i];
-  };
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  load_tiles();
-  store_tiles(0);
-  __syncthreads();
-
-  const int fr = lane & 15, fq = lane >> 4;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < ksteps) {
-      advance_k();
-      load_tiles();  // in flight during the MFMA block below
-    }
-    const char* a = smem + cur * (A_BYTES + B_BYTES);
-    const char* b = a + A_BYTES;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[WM], bfr[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-        af[i] = *reinterpret_cast<const bf16x8*>(a + lds_off(wm * (16 * WM) + i * 16 + fr, s * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(b + lds_off(wn * (16 * WN) + j * 16 + fr, s * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    if (ks + 1 < ksteps) {
-      store_tiles(cur ^ 1);
-      __syncthreads();
-    }
-  }
-
-  // ---- split-K: raw partial sums, the epilogue runs in igemm_splitk_reduce_kernel
-  if (p.ksplit > 1) {
-    float* slab = p.partial + (long long)blockIdx.y * p.M * p.Cout;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int c = cout0 + wm * (16 * WM) + i * 16 + fq * 4;
-        if (c >= p.Cout) continue;
-        *reinterpret_cast<float4*>(slab + (long long)m * p.Cout + c) =
-            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      }
-    }
-    return;
-  }
-  // ---- epilogue: D[row = cout (fq*4+r)][col = position fr]
-  const bool relu = p.epi & TRACE_EPI_RELU;
-  const bool leaky = p.epi & TRACE_EPI_LEAKY;
-  const bool res_post = (p.epi & TRACE_EPI_RES_POST) && p.res;
-  const bool has_res = (p.epi & TRACE_EPI_RESIDUAL) && p.res;
-  const bool out_f32 = p.epi & TRACE_EPI_OUT_F32;
-  const long long obase = (long long)blockIdx.z * p.bs_out;
-#pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const int c = cout0 + wm * (16 * WM) + i * 16 + fq * 4;
-      if (c >= p.Cout) continue;  // Cout % 4 == 0 is required by the host wrapper
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * p.alpha;
-      if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(p.bias + c);
-        v[0] += bv.x;
-        v[1] += bv.y;
-        v[2] += bv.z;
-        v[3] += bv.w;
-      }
-      const long long o = obase + (long long)m * p.ldo + c;
-      if (has_res) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
-        v[0] += __uint_as_float(rv.x << 16);
-        v[1] += __uint_as_float(rv.x & 0xffff0000u);
-        v[2] += __uint_as_float(rv.y << 16);
-        v[3] += __uint_as_float(rv.y & 0xffff0000u);
-      }
-      if (relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (leaky) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
-      }
-      if (res_post) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
-        v[0] += __uint_as_float(rv.x << 16);
-        v[1] += __uint_as_float(rv.x & 0xffff0000u);
-        v[2] += __uint_as_float(rv.y << 16);
-        v[3] += __uint_as_float(rv.y & 0xffff0000u);
-      }
-      if (out_f32) {
-        *reinterpret_cast<float4*>((float*)p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 ov;
-        ov.x = pack_bf16x2(v[0], v[1]);
-        ov.y = pack_bf16x2(v[2], v[3]);
-        *reinterpret_cast<uint2*>((uint16_t*)p.out + o) = ov;
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,6 +303,8 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
   const bool res_post = (p.epi & TRACE_EPI_RES_POST) && p.res;
   const bool has_res = (p.epi & TRACE_EPI_RESIDUAL) && p.res;
   const bool out_f32 = p.epi & TRACE_EPI_OUT_F32;
+  const bool res_f32 = p.epi & TRACE_EPI_RES_F32;
+  const float* bias = p.bias ? p.bias + (long long)blockIdx.z * p.bs_bias : nullptr;
   const long long obase = (long long)blockIdx.z * p.bs_out;
   // loads use clamped (always valid) addresses so that they need no per-lane branch; only the store
   // is predicated.  Cout % 8 == 0 is required by the host wrapper.
@@ -556,17 +324,22 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
       const bool cok = c < p.Cout;
       const int cl = min(c, p.Cout - 4);
       float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + cl);
+      if (bias) bq = *reinterpret_cast<const float4*>(bias + cl);
       const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         float v[4], rf[4] = {0.f, 0.f, 0.f, 0.f};
         if (has_res || res_post) {
-          const uint2 rv = *reinterpret_cast<const uint2*>(p.res + orow[j] + cl);
-          rf[0] = __uint_as_float(rv.x << 16);
-          rf[1] = __uint_as_float(rv.x & 0xffff0000u);
-          rf[2] = __uint_as_float(rv.y << 16);
-          rf[3] = __uint_as_float(rv.y & 0xffff0000u);
+          if (res_f32) {
+            const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + orow[j] + cl);
+            rf[0] = r0.x; rf[1] = r0.y; rf[2] = r0.z; rf[3] = r0.w;
+          } else {
+            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + orow[j] + cl);
+            rf[0] = __uint_as_float(rv.x << 16);
+            rf[1] = __uint_as_float(rv.x & 0xffff0000u);
+            rf[2] = __uint_as_float(rv.y << 16);
+            rf[3] = __uint_as_float(rv.y & 0xffff0000u);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -586,6 +359,17 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
             ov.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>((uint16_t*)p.out + o) = ov;
           }
+          if (p.out2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (p.epi2 & TRACE_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+              if (p.epi2 & TRACE_EPI_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+            }
+            uint2 ov;
+            ov.x = pack_bf16x2(v[0], v[1]);
+            ov.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.out2 + o) = ov;
+          }
         }
       }
     }
@@ -597,19 +381,40 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
     const bool cok = c < p.Cout;
     const int cl = min(c, p.Cout - 8);
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cl);
-      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cl + 4);
+    if (bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + cl);
+      const float4 b1 = *reinterpret_cast<const float4*>(bias + cl + 4);
       bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
       bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
-    uint4 rv[WN];
+    float rf[WN][8];
     if (has_res || res_post) {
+      if (res_f32) {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) rv[j] = *reinterpret_cast<const uint4*>(p.res + orow[j] + cl);
+        for (int j = 0; j < WN; ++j) {
+          const float* rp = reinterpret_cast<const float*>(p.res) + orow[j] + cl;
+          const float4 r0 = *reinterpret_cast<const float4*>(rp);
+          const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+          rf[j][0] = r0.x; rf[j][1] = r0.y; rf[j][2] = r0.z; rf[j][3] = r0.w;
+          rf[j][4] = r1.x; rf[j][5] = r1.y; rf[j][6] = r1.z; rf[j][7] = r1.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(p.res + orow[j] + cl);
+          const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            rf[j][2 * r] = __uint_as_float(rw[r] << 16);
+            rf[j][2 * r + 1] = __uint_as_float(rw[r] & 0xffff0000u);
+          }
+        }
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < WN; ++j) rv[j] = make_uint4(0, 0, 0, 0);
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rf[j][r] = 0.f;
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -619,16 +424,9 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
         v[r] = acc[2 * q][j][r] * p.alpha + bv[r];
         v[4 + r] = acc[2 * q + 1][j][r] * p.alpha + bv[4 + r];
       }
-      const uint32_t rw[4] = {rv[j].x, rv[j].y, rv[j].z, rv[j].w};
-      float rf[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        rf[2 * r] = __uint_as_float(rw[r] << 16);
-        rf[2 * r + 1] = __uint_as_float(rw[r] & 0xffff0000u);
-      }
       if (has_res) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rf[r];
+        for (int r = 0; r < 8; ++r) v[r] += rf[j][r];
       }
       if (relu) {
 #pragma unroll
@@ -640,7 +438,7 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
       }
       if (res_post) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += rf[r];
+        for (int r = 0; r < 8; ++r) v[r] += rf[j][r];
       }
       if (mok[j] && cok) {
         const long long o = orow[j] + c;
@@ -655,6 +453,22 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
           ov.z = pack_bf16x2(v[4], v[5]);
           ov.w = pack_bf16x2(v[6], v[7]);
           *reinterpret_cast<uint4*>((uint16_t*)p.out + o) = ov;
+        }
+        if (p.out2) {
+          if (p.epi2 & TRACE_EPI_RELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if (p.epi2 & TRACE_EPI_LEAKY) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+          }
+          uint4 ov;
+          ov.x = pack_bf16x2(v[0], v[1]);
+          ov.y = pack_bf16x2(v[2], v[3]);
+          ov.z = pack_bf16x2(v[4], v[5]);
+          ov.w = pack_bf16x2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(p.out2 + o) = ov;
         }
       }
     }
@@ -686,11 +500,19 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
   }
   const long long o = (long long)m * p.ldo + c;
   auto add_res = [&]() {
-    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
-    v[0] += __uint_as_float(rv.x << 16);
-    v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16);
-    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+    if (p.epi & TRACE_EPI_RES_F32) {
+      const float4 r0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.res) + o);
+      v[0] += r0.x;
+      v[1] += r0.y;
+      v[2] += r0.z;
+      v[3] += r0.w;
+    } else {
+      const uint2 rv = *reinterpret_cast<const uint2*>(p.res + o);
+      v[0] += __uint_as_float(rv.x << 16);
+      v[1] += __uint_as_float(rv.x & 0xffff0000u);
+      v[2] += __uint_as_float(rv.y << 16);
+      v[3] += __uint_as_float(rv.y & 0xffff0000u);
+    }
   };
   if ((p.epi & TRACE_EPI_RESIDUAL) && p.res) add_res();
   if (p.epi & TRACE_EPI_RELU) {
@@ -709,6 +531,17 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
     ov.x = pack_bf16x2(v[0], v[1]);
     ov.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>((uint16_t*)p.out + o) = ov;
+  }
+  if (p.out2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (p.epi2 & TRACE_EPI_RELU) v[r] = fmaxf(v[r], 0.f);
+      if (p.epi2 & TRACE_EPI_LEAKY) v[r] = v[r] > 0.f ? v[r] : 0.1f * v[r];
+    }
+    uint2 ov;
+    ov.x = pack_bf16x2(v[0], v[1]);
+    ov.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(p.out2 + o) = ov;
   }
 }
 
@@ -755,7 +588,6 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
       p.partial = (float*)p.ws;
     }
   }
-  static const bool use_v1 = getenv("TRACE_IGEMM_V1") != nullptr;
   const dim3 grid((unsigned)nblk, p.ksplit, batch);
   // ring depth: 2 stages keep the most workgroups per CU (they overlap each other's load latency)
   int nst = nst_req ? nst_req : 2;
@@ -763,9 +595,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
   if (nst > 4) nst = 4;
   const size_t stage = (size_t)(TC + TP) * 128;
   while (nst > 2 && nst * stage > 160 * 1024) --nst;  // 160 KiB of LDS per CU
-  if (use_v1) {
-    hipLaunchKernelGGL((igemm_bf16_kernel<WM, WN>), grid, dim3(256), 2 * stage, s, p);
-  } else {
+  {
 #define TRACE_IGEMM2(D, S)                                                                               \
   do {                                                                                                   \
     static bool attr_done = false; /* > 64 KiB of dynamic LDS must be opted into once per kernel */      \
@@ -915,30 +745,34 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
   return launch_igemm(p, 1, (hipStream_t)stream);
 }
 
-extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda,
-                                  int ldb, int ldc, int batch, long long strideA, long long strideB,
-                                  long long strideC, float alpha, const float* bias,
-                                  const uint16_t* residual, int epilogue, void* C, void* workspace,
-                                  size_t workspace_bytes, trace_stream_t stream) {
+static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda, int ldb, int ldc, int batch,
+                     long long strideA, long long strideB, long long strideC, float alpha, const float* bias,
+                     long long strideBias, const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
+                     void* workspace, size_t workspace_bytes, trace_stream_t stream) {
   TRACE_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   if (M == 0 || N == 0 || batch == 0) return 0;
   TRACE_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm: K, lda, ldb must be multiples of 8");
   TRACE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "gemm: N and ldc must be multiples of 4");
-  TRACE_REQUIRE(strideA % 8 == 0 && strideB % 8 == 0 && strideC % 4 == 0, "gemm: batch strides misaligned");
+  TRACE_REQUIRE(strideA % 8 == 0 && strideB % 8 == 0 && strideC % 4 == 0 && strideBias % 4 == 0,
+                "gemm: batch strides misaligned");
   TRACE_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm: leading dimensions too small");
   TRACE_REQUIRE(batch <= 65535, "gemm: batch too large");
   TRACE_REQUIRE(A && Bm && C, "gemm: null pointer");
   TRACE_REQUIRE(!(epilogue & (TRACE_EPI_RESIDUAL | TRACE_EPI_RES_POST)) || residual,
                 "gemm: residual flag without pointer");
-  TRACE_REQUIRE((((uintptr_t)A | (uintptr_t)Bm | (uintptr_t)C | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
+  TRACE_REQUIRE((epilogue2 & ~(TRACE_EPI_RELU | TRACE_EPI_LEAKY)) == 0, "gemm: epilogue2 takes RELU / LEAKY only");
+  TRACE_REQUIRE((((uintptr_t)A | (uintptr_t)Bm | (uintptr_t)C | (uintptr_t)C2 | (uintptr_t)residual | (uintptr_t)bias) & 15) == 0,
                 "gemm: pointers must be 16-byte aligned");
   IgemmParams p;
   memset(&p, 0, sizeof(p));
   p.in = A;
   p.w = Bm;
   p.bias = bias;
-  p.res = residual;
+  p.bs_bias = strideBias;
+  p.res = (const uint16_t*)residual;
   p.out = C;
+  p.out2 = C2;
+  p.epi2 = epilogue2;
   p.M = M;
   p.Cout = N;
   p.Crun = K;
@@ -957,4 +791,23 @@ extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, 
   p.ws = (batch == 1 && !((uintptr_t)workspace & 15)) ? workspace : nullptr;
   p.ws_bytes = workspace_bytes;
   return launch_igemm(p, batch, (hipStream_t)stream);
+}
+
+extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda,
+                                  int ldb, int ldc, int batch, long long strideA, long long strideB,
+                                  long long strideC, float alpha, const float* bias,
+                                  const uint16_t* residual, int epilogue, void* C, void* workspace,
+                                  size_t workspace_bytes, trace_stream_t stream) {
+  TRACE_REQUIRE(!(epilogue & TRACE_EPI_RES_F32), "gemm: TRACE_EPI_RES_F32 needs trace_gemm_bf16_nt_ex");
+  return gemm_impl(A, Bm, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, 0, residual, epilogue,
+                   C, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int trace_gemm_bf16_nt_ex(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda, int ldb,
+                                     int ldc, int batch, long long strideA, long long strideB, long long strideC,
+                                     float alpha, const float* bias, long long strideBias, const void* residual,
+                                     int epilogue, void* C, uint16_t* C2, int epilogue2, void* workspace,
+                                     size_t workspace_bytes, trace_stream_t stream) {
+  return gemm_impl(A, Bm, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, strideBias, residual,
+                   epilogue, C, C2, epilogue2, workspace, workspace_bytes, stream);
 }

@@ -190,9 +190,9 @@ class Generalized_RCNN(nn.Module):
                 b = F.pad(b, (0, mult - n % mult))
         return w, b
 
-    def _lin_w(self, key, layers, perm_hw_c=None):
+    def _lin_w(self, key, layers, perm_hw_c=None, pad_bias=0.0):
         """Packed (W bf16 (Np,Kp), bias f32 (Np) | None, N) of one Linear / 1x1 conv or several
-        stacked along the output dimension."""
+        stacked along the output dimension.  `pad_bias` fills the bias of the padding rows (Np > N)."""
         def make():
             ws, bs = [], []
             for l in layers:
@@ -203,22 +203,42 @@ class Generalized_RCNN(nn.Module):
                 ws.append(w)
                 bs.append(l.bias.detach().float() if l.bias is not None else torch.zeros(w.shape[0], device=w.device))
             w = torch.cat(ws, 0)
-            b = torch.cat(bs, 0) if any(l.bias is not None for l in layers) else None
+            b = torch.cat(bs, 0) if (any(l.bias is not None for l in layers) or pad_bias != 0.0) else None
             n = w.shape[0]
             w, b = self._pad_n(self._pad_k(w), b)
+            if b is not None and pad_bias != 0.0:
+                b[n:] = pad_bias
             return w.to(torch.bfloat16).contiguous(), (b.contiguous() if b is not None else None), n
         return self._cached(key, make)
 
-    def _gemm(self, x, key, layers, perm_hw_c=None, **kw):
-        """x (M,K) -> (M,N) through the bf16 MFMA GEMM; pads K / slices N as needed."""
-        w, b, n = self._lin_w(key, layers, perm_hw_c)
+    def _stack_w(self, key, layers):
+        """Same-shaped Linears as ONE batched GEMM operand: (W bf16 (b,Np,Kp), bias f32 (b,Np), N)."""
+        def make():
+            ws, bs = [], []
+            for l in layers:
+                w = l.weight.detach().float().reshape(l.weight.shape[0], -1)
+                b = l.bias.detach().float() if l.bias is not None else torch.zeros(w.shape[0], device=w.device)
+                w, b = self._pad_n(self._pad_k(w), b)
+                ws.append(w)
+                bs.append(b)
+            return torch.stack(ws).to(torch.bfloat16).contiguous(), torch.stack(bs).contiguous(), layers[0].weight.shape[0]
+        return self._cached(key, make)
+
+    def _gemm(self, x, key, layers, perm_hw_c=None, keep_pad=False, pad_bias=0.0, **kw):
+        """x (M,K) -> (M,N) through the bf16 MFMA GEMM; pads K / slices N as needed (keep_pad: keep the
+        N-padding columns).  With out2=... returns (y, y2)."""
+        w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)
         x = _bf(x)
         if x.shape[-1] != w.shape[1]:
             x = F.pad(x, (0, w.shape[1] - x.shape[-1]))
         if x.stride(-1) != 1:
             x = x.contiguous()
         y = ops.gemm_nt(x, w, bias=b, **kw)
-        return y if y.shape[-1] == n else y[..., :n]
+        if keep_pad or w.shape[0] == n:
+            return y
+        if isinstance(y, tuple):
+            return tuple(t[..., :n] for t in y)
+        return y[..., :n]
 
     def _tree_weights(self):
         def make():
@@ -235,14 +255,19 @@ class Generalized_RCNN(nn.Module):
         return self._cached("tree", make)
 
     def _ffn12_w(self):
-        """Per group (FFN1 | FFN2) stacked along K with bias b1+b2 (cluster_tree.py:203)."""
+        """FFN1(h) + FFN2(hd) of every group (cluster_tree.py:203) as ONE GEMM over [h | hd]: block-diagonal
+        weight (fc, 2*fc) - group g reads h[:, g] and hd[:, g] only - with bias b1 + b2."""
         def make():
-            out = []
-            for tm in self.cluster_tree3d.tree_message_passing_list:
-                w = torch.cat([tm.FFN1[0].weight.detach().float(), tm.FFN2[0].weight.detach().float()], 1)
-                b = tm.FFN1[0].bias.detach().float() + tm.FFN2[0].bias.detach().float()
-                out.append((w.to(torch.bfloat16).contiguous(), b.contiguous()))
-            return out
+            tms = self.cluster_tree3d.tree_message_passing_list
+            G = len(tms)
+            gw, hd = tms[0].FFN1[0].weight.shape
+            w = torch.zeros((G * gw, 2 * G * hd), device=tms[0].FFN1[0].weight.device)
+            bs = []
+            for g, tm in enumerate(tms):
+                w[g * gw:(g + 1) * gw, g * hd:(g + 1) * hd] = tm.FFN1[0].weight.detach().float()
+                w[g * gw:(g + 1) * gw, G * hd + g * hd:G * hd + (g + 1) * hd] = tm.FFN2[0].weight.detach().float()
+                bs.append(tm.FFN1[0].bias.detach().float() + tm.FFN2[0].bias.detach().float())
+            return w.to(torch.bfloat16).contiguous(), torch.cat(bs).contiguous()
         return self._cached("ffn12", make)
 
     # ------------------------------------------------------------------ host-side roi lists
@@ -383,6 +408,8 @@ class Generalized_RCNN(nn.Module):
                   X=upl.add(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]).astype(np.int64)),
                   Y=upl.add(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]).astype(np.int64)),
                   LCA=upl.add(np.concatenate([p[2] + moff[b] for b, p in enumerate(pairs)]).astype(np.int64)),
+                  X32=upl.add(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]).astype(np.int32)),
+                  Y32=upl.add(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]).astype(np.int32)),
                   union=upl.add(np.concatenate([p[3] for p in pairs], 0)),
                   t_obj=upl.add(np.concatenate(t_obj, 0)), t_reg=upl.add(np.concatenate(t_reg, 0)),
                   reg=upl.add(np.concatenate(reg_rois, 0)),
@@ -421,39 +448,41 @@ class Generalized_RCNN(nn.Module):
                 side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
             side.wait_stream(main)
         with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
-            # detection heads (:742-743, :938-952)
+            # detection heads (:742-743, :938-952).  f32 values that feed a Linear come out of the producing
+            # GEMM a second time as bf16 (with the consumer's ReLU / LeakyReLU applied): no cast / act launches
             pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
             pooled = pooled.view(Ntot, ps * ps * C)
             h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True)
-            ori = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True)
-            det_s = self._gemm(h1[:, D:2 * D], "s_fc2", [self.S_Head.fc2], out_f32=True)   # NO_FC7_RELU
-            det_o = self._gemm(h1[:, 2 * D:], "o_fc2", [self.O_Head.fc2], out_f32=True)
-            if not cfg.NO_FC7_RELU:
-                det_s, det_o = F.relu(det_s), F.relu(det_o)
-            cls = F.softmax(self._gemm(F.relu(ori), "cls", [self.Box_Outs.cls_score], out_f32=True), dim=1)
+            ori, ori_relu = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True, out2="relu")
+            w_so, b_so, _ = self._stack_w("so_fc2", [self.S_Head.fc2, self.O_Head.fc2])
+            det_so, det_so_bf = ops.gemm_nt(h1.view(Ntot, 3, D)[:, 1:].permute(1, 0, 2), w_so, bias=b_so, out_f32=True,
+                                            relu=not cfg.NO_FC7_RELU, out2="none")      # S_Head | O_Head fc2, one launch
+            # class scores: the N-padding columns get a -1e30 bias, so the softmax over the padded row is exact
+            cls_pad = F.softmax(self._gemm(ori_relu, "cls", [self.Box_Outs.cls_score], out_f32=True, keep_pad=True,
+                                           pad_bias=-1e30), dim=1)
+            cls = cls_pad[:, :cfg.NUM_CLASSES]
             det_scores, det_labels = cls[:, 1:].max(dim=1)                           # :903-904
             det_labels = det_labels + 1
-            emb = self._gemm(cls, "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], out_f32=True, leaky=True)
-            det_feat = ori + self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True)  # :945-946
+            emb = self._gemm(ops.act_cast(cls_pad), "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], leaky=True)
+            det_feat, det_feat_bf = self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True,
+                                               residual=ori, out2="none")             # :945-946
             # regions (:222-245)
             reg_map = ops.roi_align_nhwc(fmap, dv[ix["reg"]], cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
             r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
-            reg_feat = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True)
+            reg_feat, reg_feat_bf = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True, out2="none")
             # K / V maps of the pair attention (:287-289, :1545-1546)
             fm2 = fmap.view(-1, fmap.shape[-1])
             kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
             vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
-            # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069)
-            low_s = self._gemm(emb[:, E:2 * E], "sem_s_e", [self.sem_s_e[1]], out_f32=True)
-            low_o = self._gemm(emb[:, 2 * E:3 * E], "sem_o_e", [self.sem_o_e[1]], out_f32=True)
-            part_s = self._gemm(det_s, "sem_s", [self.sem_s[0]], out_f32=True)
-            part_o = self._gemm(det_o, "sem_o", [self.sem_o[0]], out_f32=True)
-            so_bias = low_s[X] + low_o[Y]
-            so_part = part_s[X] + part_o[Y]
-            sbj_lab_all, obj_lab_all = det_labels[X], det_labels[Y]
-            sbj_sc_all, obj_sc_all = det_scores[X], det_scores[Y]
-            if cfg.USE_FREQ_BIAS:
-                so_part = so_part + self.freq_bias.rel_index_with_labels(torch.stack((sbj_lab_all - 1, obj_lab_all - 1), 1))  # :1064,:1075
+            # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
+            # object Linears run as 2-batch GEMMs, the per-pair gathers + sums + frequency bias as one kernel
+            w_se, b_se, _ = self._stack_w("sem_so_e", [self.sem_s_e[1], self.sem_o_e[1]])
+            lows = ops.gemm_nt(emb.view(Ntot, 3, E)[:, 1:].permute(1, 0, 2), w_se, bias=b_se, out_f32=True)
+            w_sm, b_sm, n_rel = self._stack_w("sem_so", [self.sem_s[0], self.sem_o[0]])
+            parts = ops.gemm_nt(det_so_bf, w_sm, bias=b_sm, out_f32=True)            # (2, Ntot, n_rel padded)
+            freq = self.freq_bias.rel_baseline.weight.detach() if cfg.USE_FREQ_BIAS else None    # :1064,:1075
+            sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all, so_bias, so_part = ops.pair_assemble(
+                det_labels, det_scores, X, Y, lows[0], lows[1], parts[0], parts[1], freq, n_rel, cfg.NUM_CLASSES - 1)
         # ---- I3D backbone (:978-981)
         i3d = self.Prd_RCNN.forward_ndhwc_graphed if graph_backbone else self.Prd_RCNN.forward_ndhwc
         tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
@@ -465,25 +494,28 @@ class Generalized_RCNN(nn.Module):
             main.wait_stream(side)
 
         # ---- cluster_tree3d: temporal object features (:158-201)
-        def temporal_branch(rois_d, cur_feat, fc, q_s_l, q_o_l, val, tag):
+        def temporal_branch(rois_d, cur_feat, cur_feat_bf, fc, q_s_l, q_o_l, val, tag):
             tvec = ops.roi_align_avg_nhwc(tm_flat, rois_d, cfg.REL_SPATIAL_SCALE, ps, 0)  # ROIAlign + box_head3d.py:60-61
-            tfeat = self._gemm(tvec, tag + "_fc2", [fc.fc2], relu=True, out_f32=True)    # (K,D), (obj,t) order
+            tfeat, tfeat_bf = self._gemm(tvec, tag + "_fc2", [fc.fc2], relu=True, out_f32=True, out2="none")  # (K,D), (obj,t) order
             k = cur_feat.shape[0]
-            qs = self._gemm(cur_feat, tag + "_qs", [q_s_l[0]], out_f32=True)
-            qo = self._gemm(tfeat, tag + "_qo", [q_o_l[0]], out_f32=True)
-            att = ops.temporal_attention(qs, qo.view(k, Tn, low), tfeat.view(k, Tn, D), 1.0 / math.sqrt(low))
+            qs = self._gemm(cur_feat_bf, tag + "_qs", [q_s_l[0]], out_f32=True)
+            qo = self._gemm(tfeat_bf, tag + "_qo", [q_o_l[0]], out_f32=True)
+            att = ops.temporal_attention(qs, qo.view(k, Tn, low), tfeat.view(k, Tn, D), 1.0 / math.sqrt(low), out_bf16=True)
             v = self._gemm(att, tag + "_v0", [val[0]], out_f32=True)
-            v = F.relu(F.layer_norm(v, (v.shape[-1],), val[1].weight, val[1].bias, val[1].eps))
-            return cur_feat + self._gemm(v, tag + "_v3", [val[3]], out_f32=True)
+            v = ops.layernorm_act(v, val[1].weight.detach(), val[1].bias.detach(), val[1].eps, "relu")
+            # cur_feat + value MLP (:201, :305); second output = the ReLU'd operand of o2c / r2c (:374-379)
+            return self._gemm(v, tag + "_v3", [val[3]], out_f32=True, residual=cur_feat, out2="relu")
 
-        obj_agg = temporal_branch(dv[ix["t_obj"]], det_feat, ct3.temporal_obj_fc, ct3.temporal_obj_atten_q_s,
-                                  ct3.temporal_obj_atten_q_o, ct3.temporal_obj_feat_val, "tobj")
+        obj_agg, obj_agg_relu = temporal_branch(dv[ix["t_obj"]], det_feat, det_feat_bf, ct3.temporal_obj_fc,
+                                                ct3.temporal_obj_atten_q_s, ct3.temporal_obj_atten_q_o,
+                                                ct3.temporal_obj_feat_val, "tobj")
         # ---- temporal region features (:268-305)
-        reg_agg = temporal_branch(dv[ix["t_reg"]], reg_feat, ct3.temporal_r_fc, ct3.temporal_r_atten_q_s,
-                                  ct3.temporal_r_atten_q_o, ct3.temporal_r_feat_val, "treg")
+        reg_agg, reg_agg_relu = temporal_branch(dv[ix["t_reg"]], reg_feat, reg_feat_bf, ct3.temporal_r_fc,
+                                                ct3.temporal_r_atten_q_s, ct3.temporal_r_atten_q_o,
+                                                ct3.temporal_r_feat_val, "treg")
         # ---- tree message passing (:307-330)
-        o2c = self._gemm(F.relu(obj_agg), "o2c", [ct3.o2c[1]], out_f32=True)
-        r2c = self._gemm(F.relu(reg_agg), "r2c", [ct3.r2c[1]], out_f32=True)
+        o2c = self._gemm(obj_agg_relu, "o2c", [ct3.o2c[1]], out_f32=True)
+        r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
         fc = ct3.feat_combine
         G = ct3.group_coeffi
         gw = fc // G
@@ -491,20 +523,19 @@ class Generalized_RCNN(nn.Module):
         x_nodes[node_obj_d] = o2c
         x_nodes[node_reg_d] = r2c
         h, hd = ops.tree_gru(x_nodes, gw, gw, G, forest, self._tree_weights(), max_tree_nodes=prep["max_tree_nodes"])
-        hcat = torch.cat([h.view(-1, G, gw), hd.view(-1, G, gw)], 2).to(torch.bfloat16)   # (nodes, G, 2*gw)
-        agg = torch.empty((Ntot + Mtot, fc), dtype=torch.bfloat16, device=dev)
-        for g, (w12, b12) in enumerate(self._ffn12_w()):
-            ops.gemm_nt(hcat[:, g, :], w12, bias=b12, relu=True, out=agg[:, g * gw:(g + 1) * gw])   # FFN1(h)+FFN2(hd), ReLU of :387
+        w12, b12 = self._ffn12_w()
+        agg = ops.gemm_nt(ops.act_cast(h, None, hd), w12, bias=b12, relu=True)   # FFN1(h)+FFN2(hd) of all groups, ReLU of :387
         pf = self._gemm(agg, "ct_ffn", [ct3.FFN[1]], leaky=True)                 # leaky: only consumers are :273-275, :310-312
         pf_obj, pf_reg = pf[node_obj_d], pf[node_reg_d]
         # ---- back in _forward (:1018-1024)
-        obj_feature = det_feat + self._gemm(pf_obj, "restore", [self.restore_obj_feat[1]], out_f32=True)
-        obj_score = F.softmax(self._gemm(F.relu(obj_feature), "cem_cls", [self.cem_Box_Outs.cls_score], out_f32=True), dim=1)
+        obj_feature, obj_feature_relu = self._gemm(pf_obj, "restore", [self.restore_obj_feat[1]], out_f32=True,
+                                                   residual=det_feat, out2="relu")
+        obj_score = F.softmax(self._gemm(obj_feature_relu, "cem_cls", [self.cem_Box_Outs.cls_score], out_f32=True), dim=1)
         # ---- target-adaptive pair attention (:1524-1612)
-        lo = F.leaky_relu(obj_feature, 0.1)
+        lo = ops.act_cast(obj_feature, "leaky")
         q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
         q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
-        s_map, o_map, v_map, so = ops.pair_attention(kmap, vmap, union_d, X, Y, q_s.contiguous(), q_o.contiguous(),
+        s_map, o_map, v_map, so = ops.pair_attention(kmap, vmap, union_d, dv[ix["X32"]], dv[ix["Y32"]], q_s, q_o,
                                                      cfg.REL_SPATIAL_SCALE, ps)
         P = union_d.shape[0]
         so = so.view(P * ps * ps, 2 * low)                                       # [s_map | o_map], written in place
@@ -514,13 +545,15 @@ class Generalized_RCNN(nn.Module):
             (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low))
         sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
         spatio_infer = self._gemm(sp.view(P, ps * ps * low), "sp_fc", [self.spatio_infer_fc[0]], (low, ps * ps), leaky=True)  # :1042 (+ leaky of :329)
-        logit_spa = self._gemm(spatio_infer, "rel_spa", [self.relation_infer_spa[2]], out_f32=True)
-        # ---- semantic branch (:1643-1668); the subject / object terms were formed on the side stream
+        # ---- semantic branch (:1643-1668) and the sum of the four logit terms (:1066-1069, + freq bias :1075):
+        # each Linear adds the running sum in its epilogue
         low_r = self._gemm(pf_reg, "sem_r", [self.sem_r[1]], out_f32=True)
-        sem = F.leaky_relu(so_bias + low_r[LCA], 0.1)
-        logit_sem = self._gemm(sem, "rel_sem", [self.relation_infer_sem[2]], out_f32=True)
-        logits = logit_spa + logit_sem + so_part                                 # :1066-1069 (+ freq bias :1075)
-        prd = torch.sigmoid(logits) if cfg.MULTI_RELATION else F.softmax(logits, dim=1)   # :1083 / :1090
+        sem = ops.gather_add_act(so_bias, low_r, LCA, "leaky")                  # low_s[X] + low_r[lca] + low_o[Y], :326 LeakyReLU
+        logit_sem = self._gemm(sem, "rel_sem", [self.relation_infer_sem[2]], out_f32=True, residual=so_part, keep_pad=True)
+        logits_pad = self._gemm(spatio_infer, "rel_spa", [self.relation_infer_spa[2]], out_f32=True, residual=logit_sem,
+                                keep_pad=True)
+        logits = logits_pad[:, :n_rel]
+        prd = (torch.sigmoid(logits_pad) if cfg.MULTI_RELATION else F.softmax(logits, dim=1))[:, :n_rel]   # :1083 / :1090
 
         # ---- gathers and the ranking run once over all clips (:1162-1182 values)
         top = None

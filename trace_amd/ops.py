@@ -282,11 +282,17 @@ def _rows(t, name):
     raise RuntimeError("%s must be 2-D or 3-D" % name)
 
 
+EPI_RES_F32 = 32
+_ACT = {None: 0, "none": 0, "relu": EPI_RELU, "leaky": EPI_LEAKY}
+
+
 def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False, leaky=False,
-            residual_post=False, out=None):
+            residual_post=False, out=None, out2=None):
     """C = alpha * A @ B^T (+bias)(+residual)(+ReLU | LeakyReLU(0.1))(+residual after the activation).
     A (M,K) or (b,M,K); B (N,K) or (b,N,K); row-strided views are accepted (last dim contiguous).
-    `out` may be a row-strided view (e.g. a column slice of a wider zero-initialised buffer)."""
+    `out` may be a row-strided view (e.g. a column slice of a wider zero-initialised buffer).
+    residual: bf16 or f32 tensor of the output's shape.  bias: (N) or, batched, (b,N).
+    out2: None, or "none" | "relu" | "leaky": also return bf16(act(C)) (the next Linear's operand) -> (C, C2)."""
     ba, M, lda, sA = _rows(A, "A")
     bb, N, ldb, sB = _rows(B, "B")
     K = A.shape[-1]
@@ -308,19 +314,35 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
     sC = out.stride(0) if out.dim() == 3 else 0
     epi = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_LEAKY if leaky else 0)
     if residual is not None:
-        residual = _bf16(residual, "residual")
-        if tuple(residual.shape) != out_shape or not out.is_contiguous():
+        L.require_gpu(residual)
+        if residual.dtype == torch.float32:
+            epi |= EPI_RES_F32
+        elif residual.dtype != torch.bfloat16:
+            raise RuntimeError("gemm_nt: residual must be bf16 or f32")
+        if tuple(residual.shape) != out_shape or not out.is_contiguous() or not residual.is_contiguous():
             raise RuntimeError("gemm_nt: residual must match a contiguous output")
         epi |= EPI_RES_POST if residual_post else EPI_RESIDUAL
+    sBias = 0
     if bias is not None:
         bias = _f32(bias, "bias")
+        if bias.dim() == 2:
+            if bias.shape[0] != b:
+                raise RuntimeError("gemm_nt: batched bias must be (b, N)")
+            sBias = bias.stride(0)
+    c2 = None
+    if out2 is not None:
+        if out2 not in _ACT:
+            raise RuntimeError("gemm_nt: out2 must be one of none/relu/leaky")
+        if not out.is_contiguous():
+            raise RuntimeError("gemm_nt: out2 needs a contiguous output")
+        c2 = torch.empty(out_shape, dtype=torch.bfloat16, device=A.device)
     ws = workspace(A.device)
     with torch.cuda.device(A.device), _span(2.0 * b * M * N * K):
-        L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
-                                           L.ptr(bias), L.ptr(residual), epi, L.ptr(out), L.ptr(ws), ws.numel(),
-                                           L.stream()),
+        L.check(L.lib().trace_gemm_bf16_nt_ex(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
+                                              L.ptr(bias), sBias, L.ptr(residual), epi, L.ptr(out), L.ptr(c2),
+                                              _ACT[out2], L.ptr(ws), ws.numel(), L.stream()),
                 "gemm_bf16_nt")
-    return out
+    return out if out2 is None else (out, c2)
 
 
 def transpose(x, pad_to=1):
@@ -389,16 +411,16 @@ def roi_align_avg_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
     return out
 
 
-def temporal_attention(qs, qo, o, inv_sqrt_d):
-    """qs (n,D), qo (n,T,D), o (n,T,K) f32 -> (n,K) f32 (cluster_tree3d.py:337-366)."""
+def temporal_attention(qs, qo, o, inv_sqrt_d, out_bf16=False):
+    """qs (n,D), qo (n,T,D), o (n,T,K) f32 -> (n,K) f32, or bf16 with out_bf16 (cluster_tree3d.py:337-366)."""
     qs, qo, o = _f32(qs), _f32(qo), _f32(o)
     n, T, D = qo.shape
     K = o.shape[2]
-    out = torch.empty((n, K), dtype=torch.float32, device=o.device)
+    out = torch.empty((n, K), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=o.device)
     with torch.cuda.device(o.device):
-        L.check(L.lib().trace_temporal_attention(L.ptr(qs), L.ptr(qo), L.ptr(o), n, T, D, K,
-                                                 float(inv_sqrt_d), L.ptr(out), L.stream()),
-                "temporal_attention")
+        L.check(L.lib().trace_temporal_attention_ex(L.ptr(qs), L.ptr(qo), L.ptr(o), n, T, D, K, float(inv_sqrt_d),
+                                                    None if out_bf16 else L.ptr(out), L.ptr(out) if out_bf16 else None,
+                                                    L.stream()), "temporal_attention")
     return out
 
 
@@ -463,8 +485,10 @@ def rank_triplets_supported(n_prd, max_pairs_per_clip, prd_k):
 def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off, max_pairs_per_clip, topk, prd_k=1):
     """task_evaluation_vg_and_vrd.py:207-228 for every clip at once.  prd (P,n_prd) f32; scores (P) f32; labels
     (P) int64; pair_off (B+1) int64 on the GPU.  Returns dict of (B, topk) tensors (rows padded with score -1)."""
-    prd, sbj_scores, obj_scores = _f32(prd), _f32(sbj_scores), _f32(obj_scores)
-    L.require_gpu(sbj_labels, obj_labels, pair_off)
+    sbj_scores, obj_scores = _f32(sbj_scores), _f32(obj_scores)
+    L.require_gpu(prd, sbj_labels, obj_labels, pair_off)
+    if prd.dtype != torch.float32 or prd.dim() != 2 or prd.stride(1) != 1:
+        raise RuntimeError("rank_triplets: prd must be (P, n_prd) f32 with contiguous rows")
     if sbj_labels.dtype != torch.int64 or obj_labels.dtype != torch.int64 or pair_off.dtype != torch.int64:
         raise RuntimeError("rank_triplets: labels and pair_off must be int64")
     sbj_labels, obj_labels, pair_off = sbj_labels.contiguous(), obj_labels.contiguous(), pair_off.contiguous()
@@ -478,8 +502,80 @@ def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off,
     top = torch.empty((B, topk), dtype=torch.float32, device=dev)
     outs = [torch.empty((B, topk), dtype=torch.int64, device=dev) for _ in range(4)]
     with torch.cuda.device(dev):
-        L.check(lib.trace_rank_triplets(L.ptr(prd), P, n_prd, L.ptr(sbj_scores), L.ptr(obj_scores), L.ptr(sbj_labels),
+        L.check(lib.trace_rank_triplets(L.ptr(prd), P, n_prd, prd.stride(0), L.ptr(sbj_scores), L.ptr(obj_scores), L.ptr(sbj_labels),
                                         L.ptr(obj_labels), L.ptr(pair_off), B, int(max_pairs_per_clip), int(prd_k),
                                         int(topk), L.ptr(top), L.ptr(outs[0]), L.ptr(outs[1]), L.ptr(outs[2]),
                                         L.ptr(outs[3]), L.ptr(ws), ws_bytes, L.stream()), "rank_triplets")
     return dict(top_scores=top, top_pair=outs[0], top_prd=outs[1], top_sbj=outs[2], top_obj=outs[3])
+
+
+def act_cast(a, act=None, b=None):
+    """bf16(act([a | b])): a (rows, wa) f32, optional b (rows, wb) f32; act None | "relu" | "leaky"."""
+    a = _f32(a)
+    rows, wa = a.shape
+    wb = 0
+    if b is not None:
+        b = _f32(b)
+        if b.shape[0] != rows:
+            raise RuntimeError("act_cast: row mismatch")
+        wb = b.shape[1]
+    out = torch.empty((rows, wa + wb), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().trace_act_cast_bf16(L.ptr(a), wa, L.ptr(b), wb, rows, _ACT[act], L.ptr(out), L.stream()), "act_cast")
+    return out
+
+
+def layernorm_act(x, gamma, beta, eps, act="relu"):
+    """bf16(act(LayerNorm(x))) over the last dim: x (rows, w) f32."""
+    x = _f32(x)
+    rows, w = x.shape
+    gamma = _f32(gamma) if gamma is not None else None
+    beta = _f32(beta) if beta is not None else None
+    out = torch.empty((rows, w), dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().trace_layernorm_act_bf16(L.ptr(x), rows, w, L.ptr(gamma), L.ptr(beta), float(eps), _ACT[act],
+                                                 L.ptr(out), L.stream()), "layernorm_act")
+    return out
+
+
+def gather_add_act(a, b, idx, act=None):
+    """bf16(act(a + b[idx])): a (rows,w) f32, b (*,w) f32, idx (rows) int64."""
+    a, b = _f32(a), _f32(b)
+    L.require_gpu(idx)
+    if idx.dtype != torch.int64 or a.shape[1] != b.shape[1] or idx.numel() != a.shape[0]:
+        raise RuntimeError("gather_add_act: bad arguments")
+    out = torch.empty(tuple(a.shape), dtype=torch.bfloat16, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().trace_gather_add_act_bf16(L.ptr(a), L.ptr(b), L.ptr(idx.contiguous()), a.shape[0], a.shape[1],
+                                                  _ACT[act], L.ptr(out), L.stream()), "gather_add_act")
+    return out
+
+
+def pair_assemble(det_labels, det_scores, X, Y, low_s, low_o, part_s, part_o, freq, n_rel, n_obj):
+    """Per-pair gathers (relpn_heads.py:113-116, model_builder_rel.py:1064-1075, 1662): returns sbj_lab, obj_lab
+    (P) int64, sbj_sc, obj_sc (P) f32, so_bias = low_s[X]+low_o[Y] (P,wl) f32, so_part = part_s[X]+part_o[Y]
+    (+ freq[(ls-1)*n_obj + lo-1]) (P,wp) f32."""
+    det_scores, low_s, low_o, part_s, part_o = _f32(det_scores), _f32(low_s), _f32(low_o), _f32(part_s), _f32(part_o)
+    L.require_gpu(det_labels, X, Y)
+    if det_labels.dtype != torch.int64 or X.dtype != torch.int64 or Y.dtype != torch.int64:
+        raise RuntimeError("pair_assemble: labels and indices must be int64")
+    if freq is not None:
+        freq = _f32(freq)
+        if freq.shape[1] != n_rel:
+            raise RuntimeError("pair_assemble: frequency table width != n_rel")
+    P = X.numel()
+    wl, wp = low_s.shape[1], part_s.shape[1]
+    dev = low_s.device
+    sl = torch.empty((P,), dtype=torch.int64, device=dev)
+    ol = torch.empty((P,), dtype=torch.int64, device=dev)
+    ss = torch.empty((P,), dtype=torch.float32, device=dev)
+    os_ = torch.empty((P,), dtype=torch.float32, device=dev)
+    so_bias = torch.empty((P, wl), dtype=torch.float32, device=dev)
+    so_part = torch.empty((P, wp), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().trace_pair_assemble(L.ptr(det_labels.contiguous()), L.ptr(det_scores), L.ptr(X.contiguous()),
+                                            L.ptr(Y.contiguous()), P, L.ptr(low_s), L.ptr(low_o), wl, L.ptr(part_s),
+                                            L.ptr(part_o), wp, L.ptr(freq), int(n_rel), int(n_obj), L.ptr(sl), L.ptr(ol),
+                                            L.ptr(ss), L.ptr(os_), L.ptr(so_bias), L.ptr(so_part), L.stream()),
+                "pair_assemble")
+    return sl, ol, ss, os_, so_bias, so_part
