@@ -77,7 +77,8 @@ __device__ __forceinline__ int lds_off(int r, int chunk) {
 // weight rows are permuted inside a 32-cout group so that a lane ends up with 8 consecutive output
 // channels of one position -> 16-byte channels-last stores / residual loads.
 // ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(256))) const uint4 g_zero_page[16] = {};
+// 4 KiB + one K-step: a halo piece's source pointer walks a whole tap (Crun <= 2048 elements) inside it
+__device__ __attribute__((aligned(256))) const uint4 g_zero_page[264] = {};
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -91,191 +92,10 @@ __device__ __forceinline__ int perm_row(int odd, int rho) { return ((rho >> 2) <
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int WN, bool DENSE, int NST>
-__global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
-  static_assert(WM % 2 == 0, "cout fragments come in pairs");
-  constexpr int TC = 32 * WM;  // cout rows per block
-  constexpr int TP = 32 * WN;  // positions per block
-  constexpr int A_BYTES = TC * 128;
-  constexpr int B_BYTES = TP * 128;
-  constexpr int STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
-  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
-  const int cout0 = tile_n * TC;
-  const int pos0 = tile_m * TP;
-
-  const uint16_t* gin = p.in + (long long)blockIdx.z * p.bs_in;
-  const uint16_t* gw = p.w + (long long)blockIdx.z * p.bs_w;
-  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
-
-  // ---- loader assignment: one LDS-DMA instruction of a wave fills 8 rows x 128 B; this lane owns
-  // physical chunk (lane&7) of row (lane>>3) of it, i.e. LOGICAL k-chunk (lane&7)^(lane>>3)
-  const int lrow = wave * 8 + (lane >> 3);      // row inside a 32-row round
-  const int kseg = (lane & 7) ^ (lane >> 3);    // logical 16-byte chunk of the K-step
-
-  const int ksteps_all = (p.Ktot + BK - 1) / BK;
-  const int ks_begin = blockIdx.y * p.ks_per;
-  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
-  int klin = ks_begin * BK + kseg * 8;
-
-  const uint16_t* wp[WM];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    // A-tile row (32*i + lrow) holds weight row cout0 + 32*(row>>5) + perm(row&31): the permutation is
-    // applied when fragments are READ, the tile itself is in natural cout order
-    int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
-    wp[i] = gw + (long long)row * p.ldw + klin;
-  }
-  // positions
-  const uint16_t* xp[WN];   // DENSE: running pointers
-  long long x_nbase[WN];
-  int x_t0[WN], x_h0[WN], x_w0[WN];
-#pragma unroll
-  for (int i = 0; i < WN; ++i) {
-    int m = pos0 + lrow + 32 * i;
-    if (DENSE) {
-      m = min(m, p.M - 1);
-      xp[i] = gin + (long long)m * p.pix + klin;
-    } else {
-      if (m < p.M) {
-        int wo = m % p.Wo;
-        int t1 = m / p.Wo;
-        int ho = t1 % p.Ho;
-        int t2 = t1 / p.Ho;
-        int to = t2 % p.To;
-        int n = t2 / p.To;
-        x_nbase[i] = (long long)n * p.in_n_stride;
-        x_t0[i] = to * p.st - p.pt;
-        x_h0[i] = ho * p.sh - p.ph;
-        x_w0[i] = wo * p.sw - p.pw;
-      } else {
-        x_nbase[i] = 0;
-        x_t0[i] = -0x40000000;
-        x_h0[i] = 0;
-        x_w0[i] = 0;
-      }
-    }
-  }
-  int kc = 0, ta = 0, tb = 0, tcw = 0;
-  if (!DENSE) {
-    const int tap = klin / p.Crun;
-    kc = klin - tap * p.Crun;
-    tcw = tap % p.kw;
-    const int t2 = tap / p.kw;
-    tb = t2 % p.kh;
-    ta = t2 / p.kh;
-  }
-
-  auto issue = [&](int stage) {
-    char* a = smem + stage * STAGE + wave * 1024;
-    char* b = a + A_BYTES;
-    const bool kvalid = klin < p.Ktot;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) glds16(kvalid ? wp[i] : zero, a + i * 4096);
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-      const uint16_t* src;
-      if (DENSE) {
-        src = kvalid ? xp[i] : zero;
-      } else {
-        int ti = x_t0[i] + ta * p.dt, hi = x_h0[i] + tb * p.dh, wi = x_w0[i] + tcw * p.dw;
-        bool ok = kvalid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
-                  (unsigned)wi < (unsigned)p.Wi;
-        long long off = x_nbase[i] + ((long long)(ti * p.Hi + hi) * p.Wi + wi) * p.pix + kc;
-        src = ok ? gin + off : zero;
-      }
-      glds16(src, b + i * 4096);
-    }
-  };
-  auto advance = [&]() {
-    klin += BK;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) wp[i] += BK;
-    if (DENSE) {
-#pragma unroll
-      for (int i = 0; i < WN; ++i) xp[i] += BK;
-    } else {
-      kc += BK;
-      while (kc >= p.Crun) {
-        kc -= p.Crun;
-        if (++tcw == p.kw) {
-          tcw = 0;
-          if (++tb == p.kh) {
-            tb = 0;
-            ++ta;
-          }
-        }
-      }
-    }
-  };
-
-  f32x4 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fq = lane >> 4;
-  // A fragment i (pair q = i>>1, odd = i&1), MFMA row fr  <-  tile row wm*16*WM + q*32 + perm_row(odd, fr)
-  int a_row[WM];
-#pragma unroll
-  for (int i = 0; i < WM; ++i) a_row[i] = wm * (16 * WM) + (i >> 1) * 32 + perm_row(i & 1, fr);
-
-  // NST-deep LDS ring: the loads of K-step ks+NST-1 are issued at step ks (into the stage read at step
-  // ks-1), so NST-2 steps stay in flight across each barrier; the wait is a counted vmcnt (never 0 in
-  // steady state) followed by a raw s_barrier (__syncthreads() would drain the LDS-DMA queue).
-  constexpr int L = WM + WN;  // LDS-DMA instructions per thread per stage
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; ++s0) {
-    if (s0 < ksteps) {
-      if (s0) advance();
-      issue(s0);
-    }
-  }
-  int cur = 0, nxt = NST - 1;
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int ahead = min(NST - 2, ksteps - 1 - ks);  // K-steps issued after ks that may stay in flight
-    if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
-    else if (NST >= 3 && ahead == 1) wait_vmcnt<L>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // step ks landed for every wave; every wave is done reading step ks-1's stage
-    if (ks + NST - 1 < ksteps) {
-      advance();
-      issue(nxt);
-    }
-    const char* a = smem + cur * STAGE;
-    const char* b = a + A_BYTES;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 af[WM], bfr[WN];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + lds_off(a_row[i], s * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-        bfr[j] = *reinterpret_cast<const bf16x8*>(b + lds_off(wn * (16 * WN) + j * 16 + fr, s * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    cur = (cur + 1 == NST) ? 0 : cur + 1;
-    nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
-  }
-
+// Epilogue shared by the main-loop variants: bias / residual / activation / (second output) / split-K slab.
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0, int pos0, int wm,
+                                               int wn, int fr, int fq) {
   // lane holds, for position fr of fragment j and pair q: couts cbase + q*32 + fq*8 + [0..7]
   // (acc[2q][j] = first four, acc[2q+1][j] = last four)
   const int cbase = cout0 + wm * (16 * WM) + fq * 8;
@@ -475,6 +295,426 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
   }
 }
 
+template <int WM, int WN, bool DENSE, int NST>
+__global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
+  static_assert(WM % 2 == 0, "cout fragments come in pairs");
+  constexpr int TC = 32 * WM;  // cout rows per block
+  constexpr int TP = 32 * WN;  // positions per block
+  constexpr int A_BYTES = TC * 128;
+  constexpr int B_BYTES = TP * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
+  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
+  const int cout0 = tile_n * TC;
+  const int pos0 = tile_m * TP;
+
+  const uint16_t* gin = p.in + (long long)blockIdx.z * p.bs_in;
+  const uint16_t* gw = p.w + (long long)blockIdx.z * p.bs_w;
+  const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero_page);
+
+  // ---- loader assignment: one LDS-DMA instruction of a wave fills 8 rows x 128 B; this lane owns
+  // physical chunk (lane&7) of row (lane>>3) of it, i.e. LOGICAL k-chunk (lane&7)^(lane>>3)
+  const int lrow = wave * 8 + (lane >> 3);      // row inside a 32-row round
+  const int kseg = (lane & 7) ^ (lane >> 3);    // logical 16-byte chunk of the K-step
+
+  const int ksteps_all = (p.Ktot + BK - 1) / BK;
+  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
+  int klin = ks_begin * BK + kseg * 8;
+
+  const uint16_t* wp[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    // A-tile row (32*i + lrow) holds weight row cout0 + 32*(row>>5) + perm(row&31): the permutation is
+    // applied when fragments are READ, the tile itself is in natural cout order
+    int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
+    wp[i] = gw + (long long)row * p.ldw + klin;
+  }
+  // positions
+  const uint16_t* xp[WN];   // DENSE: running pointers
+  long long x_nbase[WN];
+  int x_t0[WN], x_h0[WN], x_w0[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    int m = pos0 + lrow + 32 * i;
+    if (DENSE) {
+      m = min(m, p.M - 1);
+      xp[i] = gin + (long long)m * p.pix + klin;
+    } else {
+      if (m < p.M) {
+        int wo = m % p.Wo;
+        int t1 = m / p.Wo;
+        int ho = t1 % p.Ho;
+        int t2 = t1 / p.Ho;
+        int to = t2 % p.To;
+        int n = t2 / p.To;
+        x_nbase[i] = (long long)n * p.in_n_stride;
+        x_t0[i] = to * p.st - p.pt;
+        x_h0[i] = ho * p.sh - p.ph;
+        x_w0[i] = wo * p.sw - p.pw;
+      } else {
+        x_nbase[i] = 0;
+        x_t0[i] = -0x40000000;
+        x_h0[i] = 0;
+        x_w0[i] = 0;
+      }
+    }
+  }
+  int kc = 0, ta = 0, tb = 0, tcw = 0;
+  if (!DENSE) {
+    const int tap = klin / p.Crun;
+    kc = klin - tap * p.Crun;
+    tcw = tap % p.kw;
+    const int t2 = tap / p.kw;
+    tb = t2 % p.kh;
+    ta = t2 / p.kh;
+  }
+
+  auto issue = [&](int stage) {
+    char* a = smem + stage * STAGE + wave * 1024;
+    char* b = a + A_BYTES;
+    const bool kvalid = klin < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) glds16(kvalid ? wp[i] : zero, a + i * 4096);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const uint16_t* src;
+      if (DENSE) {
+        src = kvalid ? xp[i] : zero;
+      } else {
+        int ti = x_t0[i] + ta * p.dt, hi = x_h0[i] + tb * p.dh, wi = x_w0[i] + tcw * p.dw;
+        bool ok = kvalid && (unsigned)ti < (unsigned)p.Ti && (unsigned)hi < (unsigned)p.Hi &&
+                  (unsigned)wi < (unsigned)p.Wi;
+        long long off = x_nbase[i] + ((long long)(ti * p.Hi + hi) * p.Wi + wi) * p.pix + kc;
+        src = ok ? gin + off : zero;
+      }
+      glds16(src, b + i * 4096);
+    }
+  };
+  auto advance = [&]() {
+    klin += BK;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) wp[i] += BK;
+    if (DENSE) {
+#pragma unroll
+      for (int i = 0; i < WN; ++i) xp[i] += BK;
+    } else {
+      kc += BK;
+      while (kc >= p.Crun) {
+        kc -= p.Crun;
+        if (++tcw == p.kw) {
+          tcw = 0;
+          if (++tb == p.kh) {
+            tb = 0;
+            ++ta;
+          }
+        }
+      }
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // A fragment i (pair q = i>>1, odd = i&1), MFMA row fr  <-  tile row wm*16*WM + q*32 + perm_row(odd, fr)
+  int a_row[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) a_row[i] = wm * (16 * WM) + (i >> 1) * 32 + perm_row(i & 1, fr);
+
+  // NST-deep LDS ring: the loads of K-step ks+NST-1 are issued at step ks (into the stage read at step
+  // ks-1), so NST-2 steps stay in flight across each barrier; the wait is a counted vmcnt (never 0 in
+  // steady state) followed by a raw s_barrier (__syncthreads() would drain the LDS-DMA queue).
+  constexpr int L = WM + WN;  // LDS-DMA instructions per thread per stage
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) {
+    if (s0 < ksteps) {
+      if (s0) advance();
+      issue(s0);
+    }
+  }
+  int cur = 0, nxt = NST - 1;
+  for (int ks = 0; ks < ksteps; ++ks) {
+    const int ahead = min(NST - 2, ksteps - 1 - ks);  // K-steps issued after ks that may stay in flight
+    if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NST >= 3 && ahead == 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // step ks landed for every wave; every wave is done reading step ks-1's stage
+    if (ks + NST - 1 < ksteps) {
+      advance();
+      issue(nxt);
+    }
+    const char* a = smem + cur * STAGE;
+    const char* b = a + A_BYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[WM], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + lds_off(a_row[i], s * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(b + lds_off(wn * (16 * WN) + j * 16 + fr, s * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+  }
+
+  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v3 main loop: same tiles, LDS image and epilogue as v2, but the K loop carries (almost) no address
+// arithmetic.  Measured on v2 (rocprofv3 SQ counters, layer4 3x3 conv): a wave spent 611 cycles per K-step
+// issuing instructions for 256 cycles of MFMA - per-piece bounds checks, 64-bit multiply-adds and LDS
+// address computations - so the matrix pipe idled behind the scalar / vector ALU work.  Here
+//   * a K-step never straddles a tap (Crun % 64 == 0): source pointers advance by 128 B per K-step and
+//     are re-derived only when the tap changes (uniform branch), from a per-piece corner offset, a
+//     per-piece tap-validity bit mask (both computed once) and a wave-uniform tap offset;
+//   * halo / tail pieces point into the zero page and advance like every other piece (no select);
+//   * fragment ds_read addresses are 6 per-lane constants + compile-time immediates: the K loop is
+//     unrolled by the ring depth so that the stage base is an immediate too;
+//   * a K tail (dense GEMMs with K % 64 != 0) is handled in the last K-step only.
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN, bool DENSE, int NST>
+__global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
+  static_assert(WM % 2 == 0, "cout fragments come in pairs");
+  constexpr int TC = 32 * WM;
+  constexpr int TP = 32 * WN;
+  constexpr int A_BYTES = TC * 128;
+  constexpr int B_BYTES = TP * 128;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = p.m_fast ? bid / p.tiles_m : bid % p.tiles_n;
+  const int tile_m = p.m_fast ? bid % p.tiles_m : bid / p.tiles_n;
+  const int cout0 = tile_n * TC;
+  const int pos0 = tile_m * TP;
+
+  const uint16_t* gin = p.in + (long long)blockIdx.z * p.bs_in;
+  const uint16_t* gw = p.w + (long long)blockIdx.z * p.bs_w;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kseg = (lane & 7) ^ (lane >> 3);
+
+  const int ksteps_all = (p.Ktot + BK - 1) / BK;
+  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
+  const int kbase = ks_begin * BK;           // uniform
+  const int klin0 = kbase + kseg * 8;        // this lane's first K element
+  // K tail: only dense problems reach here with Ktot % 64 != 0; the tail K-step is the global last one
+  const bool has_tail = DENSE && (p.Ktot & (BK - 1)) != 0 && (ks_begin + ksteps == ksteps_all);
+  const bool lane_tail = (ksteps_all - 1) * BK + kseg * 8 >= p.Ktot;
+
+  const char* ap[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
+    ap[i] = reinterpret_cast<const char*>(gw + (long long)row * p.ldw + klin0);
+  }
+  const char* bp[WN];
+  long long boff[WN];      // conv: element offset of the receptive field's corner (+ this lane's k chunk)
+  unsigned bmask[WN];      // conv: bit `tap` set <=> that tap of this position lies inside the input
+  int tap = 0, tap_left = 0x7fffffff;
+  int ta = 0, tb = 0, tcw = 0;
+  if (DENSE) {
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int m = min(pos0 + lrow + 32 * i, p.M - 1);
+      bp[i] = reinterpret_cast<const char*>(gin + (long long)m * p.pix + klin0);
+    }
+  } else {
+    const int ntaps = p.kt * p.kh * p.kw;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      const int m = pos0 + lrow + 32 * i;
+      unsigned mask = 0;
+      long long off = 0;
+      if (m < p.M) {
+        const int wo = m % p.Wo;
+        const int t1 = m / p.Wo;
+        const int ho = t1 % p.Ho;
+        const int t2 = t1 / p.Ho;
+        const int to = t2 % p.To;
+        const int n = t2 / p.To;
+        const int t0 = to * p.st - p.pt, h0 = ho * p.sh - p.ph, w0 = wo * p.sw - p.pw;
+        off = (long long)n * p.in_n_stride + ((long long)(t0 * p.Hi + h0) * p.Wi + w0) * p.pix + kseg * 8;
+        int tp = 0;
+        for (int a = 0; a < p.kt; ++a)
+          for (int b = 0; b < p.kh; ++b)
+            for (int c = 0; c < p.kw; ++c, ++tp) {
+              const bool ok = (unsigned)(t0 + a * p.dt) < (unsigned)p.Ti && (unsigned)(h0 + b * p.dh) < (unsigned)p.Hi &&
+                              (unsigned)(w0 + c * p.dw) < (unsigned)p.Wi;
+              mask |= ok ? (1u << tp) : 0u;
+            }
+      }
+      boff[i] = off;
+      bmask[i] = mask;
+    }
+    (void)ntaps;
+    const int steps_per_tap = p.Crun / BK;
+    tap = __builtin_amdgcn_readfirstlane(ks_begin / steps_per_tap);
+    const int in_tap = ks_begin - tap * steps_per_tap;
+    tap_left = steps_per_tap - in_tap;
+    tcw = tap % p.kw;
+    const int t2 = tap / p.kw;
+    tb = t2 % p.kh;
+    ta = t2 / p.kh;
+    const long long tap_off = ((long long)(ta * p.dt * p.Hi + tb * p.dh) * p.Wi + tcw * p.dw) * p.pix + in_tap * BK;
+    const uint16_t* gtap = gin + tap_off;
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      bp[i] = ((bmask[i] >> tap) & 1u) ? reinterpret_cast<const char*>(gtap + boff[i]) : zero;
+  }
+
+  // wave-uniform tap walk: the tap's element offset moves by one of three precomputed increments
+  const long long inc_w = (long long)p.dw * p.pix;
+  const long long inc_h = ((long long)p.dh * p.Wi - (long long)p.kw * p.dw) * p.pix + inc_w;
+  const long long inc_t = (((long long)p.dt * p.Hi - (long long)p.kh * p.dh) * p.Wi) * p.pix + inc_h;
+  const uint16_t* gtap_cur = nullptr;
+  if (!DENSE) gtap_cur = gin + ((long long)(ta * p.dt * p.Hi + tb * p.dh) * p.Wi + tcw * p.dw) * p.pix;
+  const int steps_per_tap_u = DENSE ? 0 : p.Crun / BK;
+  auto next_tap = [&]() {   // uniform: every lane of the workgroup changes tap at the same K-step
+    ++tap;
+    long long inc = inc_w;
+    if (++tcw == p.kw) {
+      tcw = 0;
+      inc = inc_h;
+      if (++tb == p.kh) {
+        tb = 0;
+        inc = inc_t;
+      }
+    }
+    gtap_cur += inc;
+    tap_left = steps_per_tap_u;
+    const unsigned bit = 1u << tap;
+#pragma unroll
+    for (int i = 0; i < WN; ++i)
+      bp[i] = (bmask[i] & bit) ? reinterpret_cast<const char*>(gtap_cur + boff[i]) : zero;
+  };
+
+  auto issue = [&](int stage, bool tail) {
+    char* a = smem + stage * STAGE + wave * 1024;
+    char* b = a + A_BYTES;
+    if (tail) {   // dense only: lanes past the end of K read zeros
+#pragma unroll
+      for (int i = 0; i < WM; ++i) glds16(lane_tail ? zero : ap[i], a + i * 4096);
+#pragma unroll
+      for (int i = 0; i < WN; ++i) glds16(lane_tail ? zero : bp[i], b + i * 4096);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      glds16(ap[i], a + i * 4096);
+      ap[i] += 2 * BK;
+    }
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      glds16(bp[i], b + i * 4096);
+      bp[i] += 2 * BK;
+    }
+    if (!DENSE) {
+      if (--tap_left == 0) next_tap();
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // per-lane fragment offsets inside a stage: [odd][s] for A (rows perm_row(odd, fr)), [s] for B (rows fr)
+  int aoffs[2][2], boffs[2];
+#pragma unroll
+  for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      aoffs[odd][s2] = lds_off(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) boffs[s2] = A_BYTES + lds_off(wn * (16 * WN) + fr, s2 * 4 + fq);
+
+  constexpr int L = WM + WN;
+  int issued = 0;   // K-steps issued so far (uniform)
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) {
+    if (s0 < ksteps) {
+      issue(s0, has_tail && s0 == ksteps - 1);
+      ++issued;
+    }
+  }
+  int ks = 0;
+  auto step = [&](int st) {   // st: ring stage of K-step ks (a constant in the unrolled main loop)
+    const int ahead = issued - ks - 1;   // K-steps issued after ks
+    if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
+    else if (NST >= 3 && ahead >= 1) wait_vmcnt<L>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (issued < ksteps) {
+      const int nst_stage = st + NST - 1;
+      issue(nst_stage >= NST ? nst_stage - NST : nst_stage, has_tail && issued == ksteps - 1);
+      ++issued;
+    }
+    const char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[WM], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(sb + aoffs[i & 1][s2] + (i >> 1) * (32 * 128));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + boffs[s2] + j * (16 * 128));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    ++ks;
+  };
+  // whole rounds of the ring with the stage as an immediate, then the remaining (< NST) steps
+  for (; ks + NST <= ksteps;) {
+#pragma unroll
+    for (int st = 0; st < NST; ++st) step(st);
+  }
+  for (int st = 0; ks < ksteps; ++st) step(st);
+  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq);
+}
+
 // Sum the split-K slabs in slice order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p) {
   const int cq = p.Cout >> 2;
@@ -547,11 +787,14 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
 
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
-  int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256
+  int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256,
+               // 8: 128c x 192p, 9: 256c x 192p, 10: 64c x 64p... (see launch_igemm)
   int nst;     // 2..4
   int ksplit;  // >= 1
 };
 static thread_local IgemmTune g_tune = {0, 0, 0};
+// TRACE_IGEMM_V2=1 keeps the v2 main loop (A/B measurements)
+static const bool g_force_v2 = getenv("TRACE_IGEMM_V2") != nullptr;
 
 template <int WM, int WN>
 static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int ksplit_req) {
@@ -574,12 +817,21 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     const long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
     if (ksplit_req > 0) {
       ks = ksplit_req;
-    } else if (nblk < 256 && ksteps >= 32) {
-      // measured (tools/tune_igemm.py): slices only pay for deep K; aim at ~2 workgroups per CU and keep
-      // >= 16 K-steps per slice (the f32 slabs and the reduce launch cost more than shallow slices return)
-      ks = (512 + nblk - 1) / nblk;
+    } else if (nblk < 256 && ksteps >= 128) {
+      // deep K (weight-streaming FCs, the 12544-wide pair FC): one wave of workgroups (~2 per CU with small
+      // tiles, 1 per CU with the big ones), >= 16 K-steps per slice; measured on cold operands
+      // (scratch/sweep_step.py): 21 slices for the 160 x 3072 x 100352 FC, 4 for 3040 x 256 x 12544
+      const long long target = (TC + TP >= 256) ? 256 : 512;
+      ks = (target + nblk / 2) / nblk;
+      if (TC + TP >= 256 && p.M <= 256 && ks < 21 && ksteps >= 1024) ks = 21;
+      if (ks > ksteps / 16) ks = ksteps / 16;
+      if (ks > 32) ks = 32;
+    } else if (nblk < 128 && ksteps >= 32) {
+      // badly under-filled grids (single-clip convs): a few slices of >= 16 K-steps each
+      ks = 256 / nblk;
       if (ks > ksteps / 16) ks = ksteps / 16;
     }
+    if (ks < 1) ks = 1;
     if (ks > ksteps) ks = ksteps;
     if (ks > cap_ws) ks = cap_ws;
     if (ks > 1) {
@@ -589,11 +841,21 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     }
   }
   const dim3 grid((unsigned)nblk, p.ksplit, batch);
-  // ring depth: 2 stages keep the most workgroups per CU (they overlap each other's load latency)
+  // ring depth.  v2 main loop: 2 stages (most workgroups per CU).  v3: the leaner K loop is latency-bound
+  // when few workgroups share a CU, so the ring goes to 3 (4 for single-workgroup-per-CU grids) whenever
+  // every workgroup of the launch still fits on the chip at once with the deeper ring.
+  const size_t stage = (size_t)(TC + TP) * 128;
+  const bool v3 = !g_force_v2 && (p.dense || (p.Crun % BK == 0 && p.Crun <= 2048 && p.kt * p.kh * p.kw <= 32));
   int nst = nst_req ? nst_req : 2;
+  if (!nst_req && v3) {
+    const long long total = nblk * p.ksplit * batch;
+    const long long per_cu = (total + 255) / 256;
+    const int ks_slice = p.ks_per;
+    if (per_cu == 1 && 4 * stage <= 160 * 1024 && ks_slice >= 8 && (TC + TP) <= 192) nst = 4;
+    else if (per_cu * 3 * stage <= 160 * 1024 && ks_slice >= 4) nst = 3;
+  }
   if (nst < 2) nst = 2;
   if (nst > 4) nst = 4;
-  const size_t stage = (size_t)(TC + TP) * 128;
   while (nst > 2 && nst * stage > 160 * 1024) --nst;  // 160 KiB of LDS per CU
   {
 #define TRACE_IGEMM2(D, S)                                                                               \
@@ -606,12 +868,31 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     }                                                                                                    \
     hipLaunchKernelGGL((igemm2_bf16_kernel<WM, WN, D, S>), grid, dim3(256), S * stage, s, p);           \
   } while (0)
-    if (p.dense) {
+#define TRACE_IGEMM3(D, S)                                                                               \
+  do {                                                                                                   \
+    static bool attr_done3 = false;                                                                      \
+    if (!attr_done3) {                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3_bf16_kernel<WM, WN, D, S>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * stage));           \
+      attr_done3 = true;                                                                                 \
+    }                                                                                                    \
+    hipLaunchKernelGGL((igemm3_bf16_kernel<WM, WN, D, S>), grid, dim3(256), S * stage, s, p);           \
+  } while (0)
+    // v3 main loop (eligibility computed above): a K-step must not straddle a tap, taps must fit the 32-bit
+    // validity mask, a halo pointer must stay inside the zero page while it walks a tap
+    if (v3) {
+      if (p.dense) {
+        if (nst == 2) TRACE_IGEMM3(true, 2); else if (nst == 3) TRACE_IGEMM3(true, 3); else TRACE_IGEMM3(true, 4);
+      } else {
+        if (nst == 2) TRACE_IGEMM3(false, 2); else if (nst == 3) TRACE_IGEMM3(false, 3); else TRACE_IGEMM3(false, 4);
+      }
+    } else if (p.dense) {
       if (nst == 2) TRACE_IGEMM2(true, 2); else if (nst == 3) TRACE_IGEMM2(true, 3); else TRACE_IGEMM2(true, 4);
     } else {
       if (nst == 2) TRACE_IGEMM2(false, 2); else if (nst == 3) TRACE_IGEMM2(false, 3); else TRACE_IGEMM2(false, 4);
     }
 #undef TRACE_IGEMM2
+#undef TRACE_IGEMM3
   }
   if (p.ksplit > 1) {
     long long n4 = (long long)p.M * (p.Cout >> 2);
@@ -631,8 +912,11 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
   if (!tile) {
     // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
     auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
+    const int ksteps = ceil_div(p.Ktot, BK);
     if (p.Cout <= 64) tile = 2;                                                   // 64 couts x 128 positions
-    else if (p.ws && batch == 1 && p.M <= 256 && p.Ktot >= 8192) tile = 4;        // weight streaming + split-K
+    else if (p.ws && batch == 1 && p.M <= 192 && ksteps >= 1024)                  // weight streaming + split-K:
+      tile = p.M <= 64 ? 3 : (p.M <= 128 ? 4 : 8);                                //   all positions in one tile
+    else if (p.ws && batch == 1 && ksteps >= 128 && blocks(128, 128) <= 128) tile = 4;   // deep K: big tiles + split-K
     else if (blocks(128, 128) >= 384) tile = 4;
     else if (blocks(128, 64) >= 384) tile = 3;
     else tile = 1;                                                                // 64 x 64: small problems
@@ -644,6 +928,8 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     case 5: return launch_cfg<4, 8>(p, batch, s, t.nst, t.ksplit);
     case 6: return launch_cfg<8, 4>(p, batch, s, t.nst, t.ksplit);
     case 7: return launch_cfg<8, 8>(p, batch, s, t.nst, t.ksplit);
+    case 8: return launch_cfg<4, 6>(p, batch, s, t.nst, t.ksplit);
+    case 9: return launch_cfg<8, 6>(p, batch, s, t.nst, t.ksplit);
     default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
   }
 }
@@ -653,7 +939,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
 using namespace trace;
 
 extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
-  TRACE_REQUIRE(tile >= 0 && tile <= 7 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
+  TRACE_REQUIRE(tile >= 0 && tile <= 9 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
   g_tune = IgemmTune{tile, nst, ksplit};
   return 0;
 }
