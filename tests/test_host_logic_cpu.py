@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 
 from conftest import synth_boxes
 
@@ -36,3 +37,27 @@ def test_ovlp_filter_equals_pair_overlap_gt_zero():
     assert 0 < len(ref) < 200 and np.array_equal(keep, np.array(ref))
     far = b + 1000.0
     assert np.array_equal(ovlp_filter(a, far), np.arange(200))       # nothing overlaps -> every pair kept (:99)
+
+
+@pytest.mark.parametrize("B,n", [(8, 20), (3, 7), (2, 1), (4, 50), (2, 2)])
+def test_batched_host_prep_is_byte_identical_to_per_clip(B, n, monkeypatch):
+    """The clip-batched host side (cluster_tree.build_trees_same_n and friends) must pack exactly the
+    bytes the per-clip restatement of cluster_tree.py:504-649 / relpn_heads.py:79-84 packs (duplicate
+    boxes included: argsort / argmin ties)."""
+    import trace_amd.model_builder_rel as mb
+    from trace_amd.synthetic import make_inputs
+    model = mb.Generalized_RCNN()
+    model.eval()
+    _, _, _, rois = make_inputs(B, 8, n, 224, seed=3)
+    if n > 3:
+        rois[1][2] = rois[1][0]
+    a = model._host_prep(rois, 4, 1.0, 1.0)
+    monkeypatch.setattr(mb, "set", lambda x: {0, 1}, raising=False)      # disables the same-n fast path
+    b = model._host_prep(rois, 4, 1.0, 1.0)
+    assert a["upl"].nbytes == b["upl"].nbytes and len(a["upl"].items) == len(b["upl"].items)
+    for (oa, xa), (ob, xb) in zip(a["upl"].items, b["upl"].items):
+        assert oa == ob and xa.dtype == xb.dtype and xa.shape == xb.shape and np.array_equal(xa, xb)
+    for k in ("sig", "Ntot", "Mtot", "n_list", "m_list", "max_tree_nodes", "forest_keys", "forest_ix", "ix"):
+        assert a[k] == b[k], k
+    for pa, pb in zip(a["pairs"], b["pairs"]):
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])

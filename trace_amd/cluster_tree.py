@@ -82,6 +82,106 @@ def build_tree(leaf_boxes, max_tree_height=7, partition=2):
     return dict(parent=parent, level_off=level_off, boxes=feat, n_leaf=n)
 
 
+def layer_sizes(n, max_tree_height=7, partition=2):
+    """Node counts of the layers above n leaves (cluster_tree.py:529-548, forced root included)."""
+    sizes = []
+    c = int(math.ceil(n))
+    for _ in range(max_tree_height):
+        c = int(math.ceil(float(c) / partition))
+        sizes.append(c)
+        if c <= 1:
+            break
+    if c > 1:
+        sizes.append(1)
+    if len(sizes) + 1 > MAX_LEVELS:
+        raise ValueError("tree deeper than %d levels" % MAX_LEVELS)
+    return sizes
+
+
+def build_trees_same_n(leaf_boxes, max_tree_height=7, partition=2):
+    """`build_tree` for B clips with the same number of boxes in one pass: leaf_boxes (B,n,4) -> dict(parent
+    (B,total) int32, level_off (shared list), boxes (B,total,4), n_leaf).  Every numpy call of the per-clip
+    version runs once over a leading clip axis; reductions keep their axis order (the density sum stays a
+    last-axis pairwise sum, argsort / argmin run per row), so each clip's tree is bit-identical."""
+    B, n = leaf_boxes.shape[0], leaf_boxes.shape[1]
+    if n <= 0:
+        raise ValueError("a clip needs at least one box")
+    sizes = layer_sizes(n, max_tree_height, partition)
+    total = n + sum(sizes)
+    feat = np.empty((B, total, 4), leaf_boxes.dtype)
+    feat[:, :n] = leaf_boxes
+    parent = np.full((B, total), -1, np.int32)
+    level_off = [0, n]
+    bi = np.arange(B)[:, None]
+    l, r = 0, n - 1
+    for k in sizes:
+        sub = feat[:, l:r + 1]
+        distance = _sqdist(sub[:, :, None, :], sub[:, None, :, :])
+        score = -np.sum(np.exp(-distance), axis=2)
+        ids = np.argsort(score, axis=1) + l
+        ids = np.concatenate((ids[:, 0::2], ids[:, 1::2]), axis=1)
+        centres, rest = ids[:, :k], ids[:, k:]
+        new_ids = np.arange(r + 1, r + 1 + k)
+        parent[bi, centres] = new_ids[None, :]
+        nb = feat[bi, centres]                          # fancy indexing: a copy
+        if rest.shape[1]:
+            rb = feat[bi, rest]
+            d = _sqdist(nb[:, :, None, :], rb[:, None, :, :])
+            owner = np.argmin(d, axis=1)
+            parent[bi, rest] = new_ids[owner]
+            bb = np.broadcast_to(bi, owner.shape)
+            np.minimum.at(nb[:, :, 0], (bb, owner), rb[:, :, 0])
+            np.minimum.at(nb[:, :, 1], (bb, owner), rb[:, :, 1])
+            np.maximum.at(nb[:, :, 2], (bb, owner), rb[:, :, 2])
+            np.maximum.at(nb[:, :, 3], (bb, owner), rb[:, :, 3])
+        feat[:, r + 1:r + 1 + k] = nb
+        l, r = r + 1, r + k
+        level_off.append(r + 1)
+    return dict(parent=parent, level_off=level_off, boxes=feat, n_leaf=n)
+
+
+def split_trees(bt):
+    """Per-clip tree dicts (views) of a `build_trees_same_n` result."""
+    return [dict(parent=bt["parent"][b], level_off=bt["level_off"], boxes=bt["boxes"][b], n_leaf=bt["n_leaf"])
+            for b in range(bt["parent"].shape[0])]
+
+
+def lca_same_n(bt, X, Y):
+    """`lca` for every clip of a `build_trees_same_n` result and one shared leaf-pair list: (B, P) node ids."""
+    n = bt["n_leaf"]
+    par = bt["parent"]
+    B = par.shape[0]
+    bi = np.arange(B)[:, None]
+    rows = [np.broadcast_to(np.arange(n), (B, n))]
+    for _ in range(len(bt["level_off"]) - 2):
+        rows.append(par[bi, rows[-1]])
+    anc = np.stack(rows, 0)                              # (levels, B, n)
+    differ = (anc[:, :, X] != anc[:, :, Y]).sum(0)       # (B, P)
+    differ = np.minimum(np.maximum(differ, 1), anc.shape[0] - 1)
+    return anc[differ, bi, X[None, :]]
+
+
+def forest_arrays_same_n(bt):
+    """`forest_arrays` of a `build_trees_same_n` result (all trees have the same node count)."""
+    par = bt["parent"]
+    B, nt = par.shape
+    base = (np.arange(B) * nt)[:, None]
+    parent = np.where(par >= 0, par + base, -1)
+    lo = np.asarray(bt["level_off"])
+    n_levels = len(lo) - 1
+    lo_pad = np.concatenate([lo, np.full(MAX_LEVELS + 1 - len(lo), lo[-1])])
+    level_off = base + lo_pad[None, :]
+    order = np.argsort(par, axis=1, kind="stable")       # the root (-1) sorts first: exactly one per tree
+    child_idx = (order[:, 1:] + base).reshape(-1)
+    counts = np.zeros((B, nt), np.int64)
+    np.add.at(counts, (np.broadcast_to(np.arange(B)[:, None], (B, nt - 1)), par[np.arange(B)[:, None], order[:, 1:]]), 1)
+    child_off = np.concatenate([[0], np.cumsum(counts.reshape(-1))])
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    return dict(tree_off=i32(np.arange(B + 1) * nt), level_off=i32(level_off).reshape(-1),
+                n_levels=i32(np.full(B, n_levels)), parent=i32(parent.reshape(-1)), child_off=i32(child_off),
+                child_idx=i32(child_idx))
+
+
 def ancestors(tree):
     """(levels, n_leaf) table: row k = ancestor of each leaf at height k (row 0 = the leaf)."""
     n = tree["n_leaf"]

@@ -166,3 +166,32 @@ extern "C" int trace_pair_assemble(const int64_t* det_labels, const float* det_s
                      so_part);
   return check_launch("pair_assemble");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-step host arrays without a copy-engine hop: the first node of a captured step reads the step's
+// packed host arrays (roi lists, forest CSR arrays, pair indices - what the reference uploads with ~20
+// blocking torch.from_numpy(..).cuda() per clip, lib/modeling_rel/model_builder_rel.py:1389,
+// lib/combine_tree/cluster_tree.py:214,730) straight from pinned host memory.  The pinned buffer holds
+// two slots; launch number k reads slot k & 1 (k lives in `counter`), so the host may fill the other
+// slot while the GPU still runs the previous step.  One workgroup: the counter is bumped after every
+// thread has read it.
+namespace trace {
+__global__ __launch_bounds__(1024) void upload_slots_kernel(const uint4* __restrict__ pinned, size_t slot_u4,
+                                                            unsigned* counter, uint4* __restrict__ dst, size_t n_u4) {
+  const unsigned seq = *counter;
+  const uint4* src = pinned + (size_t)(seq & 1u) * slot_u4;
+  for (size_t i = threadIdx.x; i < n_u4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = seq + 1u;
+}
+}  // namespace trace
+
+extern "C" int trace_upload_slots(const void* pinned, size_t slot_bytes, unsigned* counter, void* dst, size_t nbytes,
+                                  trace_stream_t stream) {
+  TRACE_REQUIRE(pinned && counter && dst, "upload_slots: null pointer");
+  TRACE_REQUIRE(slot_bytes % 16 == 0 && nbytes % 16 == 0 && nbytes <= slot_bytes, "upload_slots: sizes must be multiples of 16, nbytes <= slot_bytes");
+  TRACE_REQUIRE((((uintptr_t)pinned | (uintptr_t)dst) & 15) == 0, "upload_slots: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(trace::upload_slots_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint4*)pinned,
+                     slot_bytes / 16, counter, (uint4*)dst, nbytes / 16);
+  return trace::check_launch("upload_slots");
+}

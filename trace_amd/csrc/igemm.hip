@@ -853,6 +853,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     const int ks_slice = p.ks_per;
     if (per_cu == 1 && 4 * stage <= 160 * 1024 && ks_slice >= 8 && (TC + TP) <= 192) nst = 4;
     else if (per_cu * 3 * stage <= 160 * 1024 && ks_slice >= 4) nst = 3;
+    else if (ksteps >= 1024 && p.M <= 256 && 3 * stage <= 160 * 1024) nst = 3;   // weight streaming: bytes in flight first
   }
   if (nst < 2) nst = 2;
   if (nst > 4) nst = 4;

@@ -509,6 +509,19 @@ def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off,
     return dict(top_scores=top, top_pair=outs[0], top_prd=outs[1], top_sbj=outs[2], top_obj=outs[3])
 
 
+def upload_slots(pinned, slot_bytes, counter, dst, nbytes):
+    """First node of a captured step: dst[:nbytes] = slot (launch count & 1) of the two-slot PINNED host
+    buffer (see trace_upload_slots); `counter` is a 1-element int32 device tensor owned by the graph."""
+    L.require_gpu(counter, dst)
+    if pinned.is_cuda or not pinned.is_pinned():
+        raise RuntimeError("upload_slots: `pinned` must be pinned host memory")
+    if pinned.numel() < 2 * slot_bytes or dst.numel() < nbytes:
+        raise RuntimeError("upload_slots: buffers too small")
+    with torch.cuda.device(dst.device):
+        L.check(L.lib().trace_upload_slots(ctypes.c_void_p(pinned.data_ptr()), slot_bytes, L.ptr(counter), L.ptr(dst),
+                                           nbytes, L.stream()), "upload_slots")
+
+
 def act_cast(a, act=None, b=None):
     """bf16(act([a | b])): a (rows, wa) f32, optional b (rows, wb) f32; act None | "relu" | "leaky"."""
     a = _f32(a)
