@@ -185,7 +185,8 @@ def sem_feat(sd, softmax_obj_vec, region_feature, lca, sbj_inds, obj_inds):
 
 
 def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale=1.0, groups=4,
-                 low_dim=256, max_tree_height=7, partition=2, conv_scale=1.0 / 16, rel_scale=1.0 / 16):
+                 low_dim=256, max_tree_height=7, partition=2, conv_scale=1.0 / 16, rel_scale=1.0 / 16,
+                 det_labels_in=None, det_scores_in=None, dataset_name="vidvrd", use_ovlp_filter=False):
     """One clip.
       blob_conv (1,2048,H,W)  Conv_Body output (model_builder_rel.py:702)
       feat_map  (1,2048,h,w)  Prd_RCNN2D output (:1006-1007)
@@ -203,7 +204,18 @@ def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale
     cls_np = cls.numpy()
     det_labels = np.argmax(cls_np[:, 1:], axis=1).astype(np.int32) + 1    # :903
     det_scores = np.amax(cls_np[:, 1:], axis=1)                           # :904
-    sbj_inds, obj_inds, rel_rois = np_oracle.relpn_pairs(det_rois)        # RelPN :906
+    if det_labels_in is not None:                                         # `prd_category` records (:895-898) /
+        det_labels = np.asarray(det_labels_in).astype(np.int32)           # prepare_det_rois output (:912-915)
+        det_scores = np.asarray(det_scores_in).astype(np.float32)
+    sbj_inds, obj_inds, rel_rois = np_oracle.relpn_pairs(det_rois, det_labels if det_labels_in is not None else None,
+                                                         dataset_name)   # RelPN :906
+    if use_ovlp_filter:                                                   # relpn_heads.py:94-105
+        sb = (det_rois[sbj_inds][:, 1:] / im_scale).astype(np.float32)
+        ob = (det_rois[obj_inds][:, 1:] / im_scale).astype(np.float32)
+        ovlp = c_oracle.bbox_pair_overlaps(sb, ob)                        # cython_bbox_rel.pyx:37-77
+        keep = np.where(ovlp > 0)[0]
+        if keep.size > 0:
+            sbj_inds, obj_inds, rel_rois = sbj_inds[keep], obj_inds[keep], rel_rois[keep]
     det_embed = _lin(sd, "embed_obj_det", cls)                            # :945
     det_feat = ori + _lin(sd, "after_obj_det_embed.1", F.leaky_relu(det_embed, 0.1))  # :946
     det_s = _two_mlp(sd, "S_Head", pooled, use_relu=False)                # :949 (NO_FC7_RELU)

@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import boxes as box_ops
 from . import cluster_tree as ct
 from . import ops
 from .config import TraceConfig, vidvrd_config
@@ -294,19 +295,26 @@ class Generalized_RCNN(nn.Module):
         return rois.reshape(-1, 5)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1):
+    def forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
+                det_labels=None, det_scores=None):
         """Inference on B clips.
           all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688)
           blob_conv  (B,2048,H/16,W/16) f32 NCHW or (B,H/16,W/16,2048) bf16 — Conv_Body(data) (:702)
           feat_map   same layouts — Prd_RCNN2D(cur frame) (:1006-1007)
           det_rois   list of B numpy (n_b,5) [*,x1,y1,x2,y2] key-frame rois (:894)
+          det_labels, det_scores   optional lists of B numpy (n_b,) arrays: labels (1-based) / scores that come
+                     WITH the boxes - the `prd_category` records of pre-computed detections (:895-898) or the
+                     detected-box branch's prepare_det_rois output (:912-915).  They then feed RelPN (on Action
+                     Genome only persons, label <= 1, are subjects: relpn_heads.py:71-77) and the pair labels /
+                     scores; without them labels / scores are the Box_Outs argmax (:900-904).
         Returns a list of B dicts with the reference's return keys (:1162-1182)."""
         if self.training:
             raise ValueError('You should call this function only on inference. '
                              'Set the network in inference mode by net.eval().')
         with torch.no_grad():
             dev = all_frames.device
-            prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale)
+            prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale,
+                                   det_labels, det_scores)
             if self.graph_step and ops.IGEMM_TRACE is None:
                 res = self._replay_step(all_frames, blob_conv, feat_map, prep, topk, prd_k)
             else:
@@ -385,7 +393,7 @@ class Generalized_RCNN(nn.Module):
             return x.contiguous()
         return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
-    def _host_prep(self, det_rois, Tn, im_scale, f_scale):
+    def _host_prep(self, det_rois, Tn, im_scale, f_scale, det_labels=None, det_scores=None):
         """Host side of a step: roi lists, box trees, pair lists (numpy, as in the reference), packed for
         one upload.  `sig` identifies every launch shape of the step."""
         cfg = self.cfg
@@ -397,7 +405,10 @@ class Generalized_RCNN(nn.Module):
                                                   np.asarray(r[:, 1:5], np.float32)], 1)
                                   for b, r in enumerate(det_rois)], 0)
         scale3d = float(1.0 * f_scale * (1.0 / im_scale))                        # :1766-1770
-        if B > 1 and len(set(n_list)) == 1:
+        if (det_labels is None) != (det_scores is None):
+            raise ValueError("det_labels and det_scores come together")
+        person_sbj = det_labels is not None and cfg.dataset.find("ag") >= 0
+        if B > 1 and len(set(n_list)) == 1 and not cfg.USE_OVLP_FILTER and det_labels is None:
             return self._host_prep_same_n(det_all, B, n_list[0], Tn, scale3d, off)
         trees, t_obj, t_reg, reg_rois, pairs = [], [], [], [], []
         m_list = []
@@ -416,7 +427,15 @@ class Generalized_RCNN(nn.Module):
             # frame; the list keeps the reference's object-major-vs-frame-major pairing (same quirk as objects)
             t_reg.append(self._temporal_roi_list(tree["boxes"][n:].astype(np.float32), Tn, b * Tn))
             reg_rois.append(np.concatenate([np.full((m, 1), b, np.float32), tree["boxes"][n:].astype(np.float32)], 1))
-            if n > 1:
+            if person_sbj or cfg.USE_OVLP_FILTER:
+                # RelPN (relpn_heads.py:71-105): person subjects on Action Genome, then the overlap filter on the
+                # boxes in original image scale
+                s, o = box_ops.relpn_pair_indices(n, det_labels[b] if person_sbj else None, cfg.dataset)
+                if cfg.USE_OVLP_FILTER:
+                    bx = (det_all[off[b]:off[b + 1], 1:5] / np.float32(im_scale)).astype(np.float32)
+                    keep = box_ops.ovlp_filter(bx[s], bx[o])
+                    s, o = s[keep], o[keep]
+            elif n > 1:
                 s = np.repeat(np.arange(n), n - 1)
                 o = np.tile(np.arange(n - 1), n)
                 o = o + (o >= s)
@@ -446,9 +465,15 @@ class Generalized_RCNN(nn.Module):
                   reg=upl.add(np.concatenate(reg_rois, 0)),
                   pclip=upl.add(np.repeat(np.arange(B), np.diff(poff)).astype(np.int64)),
                   poff=upl.add(poff.astype(np.int64)))
+        if det_labels is not None:
+            lab = np.concatenate([np.asarray(l).reshape(-1) for l in det_labels]).astype(np.int64)
+            sc = np.concatenate([np.asarray(v).reshape(-1) for v in det_scores]).astype(np.float32)
+            if lab.shape[0] != Ntot or sc.shape[0] != Ntot:
+                raise ValueError("det_labels / det_scores must hold one entry per roi")
+            ix["lab"], ix["sc"] = upl.add(lab), upl.add(sc)
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list)),
+                    sig=(Tn, tuple(n_list), tuple(m_list), tuple(len(p[0]) for p in pairs), det_labels is not None),
                     max_tree_nodes=max(n + m for n, m in zip(n_list, m_list)))
 
     def _host_prep_same_n(self, det_all, B, n, Tn, scale3d, off):
@@ -511,7 +536,7 @@ class Generalized_RCNN(nn.Module):
         n_list = [n] * B
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=B * n, Mtot=B * m,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list)), max_tree_nodes=n + m)
+                    sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False), max_tree_nodes=n + m)
 
     def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone):
         """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
@@ -554,8 +579,11 @@ class Generalized_RCNN(nn.Module):
             cls_pad = F.softmax(self._gemm(ori_relu, "cls", [self.Box_Outs.cls_score], out_f32=True, keep_pad=True,
                                            pad_bias=-1e30), dim=1)
             cls = cls_pad[:, :cfg.NUM_CLASSES]
-            det_scores, det_labels = cls[:, 1:].max(dim=1)                           # :903-904
-            det_labels = det_labels + 1
+            if "lab" in ix:                                                          # labels / scores came with the boxes (:895-898)
+                det_labels, det_scores = dv[ix["lab"]], dv[ix["sc"]]
+            else:
+                det_scores, det_labels = cls[:, 1:].max(dim=1)                       # :903-904
+                det_labels = det_labels + 1
             emb = self._gemm(ops.act_cast(cls_pad), "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], leaky=True)
             det_feat, det_feat_bf = self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True,
                                                residual=ori, out2="none")             # :945-946
