@@ -150,12 +150,21 @@ def main():
     value = world * B * args.steps / dt
     roof = None
     if trace:
-        ms = [s.elapsed_time(e) for s, e, _ in trace]
-        fl = [f for _, _, f in trace]
+        ms = [t[0].elapsed_time(t[1]) for t in trace]
+        fl = [t[2] for t in trace]
+        alg_bytes = sum(t[3] for t in trace) / len(trace)
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over
+        # this same command, tools/pmc_traffic.py): bench.py cannot run under the profiler itself, so it quotes
+        # the committed summary of the current round
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
+        if os.path.exists(tp):
+            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
         avg_ms = sum(ms) / len(ms)
         achieved = (sum(fl) / len(fl)) / (avg_ms * 1e-3)      # avg algorithmic FLOPs per launch / avg launch duration
         roof = dict(bound="mfma", achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
-                    frac=achieved / MFMA_BF16_PEAK, traffic=None, kernel="trace::igemm_bf16_kernel<*>",
+                    frac=achieved / MFMA_BF16_PEAK, traffic=traffic, traffic_unit="bytes per launch (PMC)",
+                    algorithmic_bytes_per_launch=alg_bytes, kernel="trace::igemm*_bf16_kernel<*>",
                     launches_per_step=len(trace) // args.steps, avg_launch_us=avg_ms * 1e3,
                     gflop_per_step=sum(fl) / args.steps / 1e9)
     cpu = None

@@ -259,6 +259,11 @@ int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int cols,
  * layouts of the two products; nkp = T*(H/2)*(W/2) rounded up to 8, padding positions are zeros. */
 int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c,
                              uint16_t* phi_p, uint16_t* gT, int nkp, trace_stream_t stream);
+/* Same, for the reassociated non-local product y = theta (phi^T g) / N_kv (dot_product mode has no softmax, so
+ * (theta phi^T) g = theta (phi^T g): the (N_q x N_kv) pairwise map is never formed): also / instead writes
+ * phi^T (N, c, nkp) next to g^T.  phi_p or phiT may be NULL (not both). */
+int trace_nl_pool_split2_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c, uint16_t* phi_p,
+                              uint16_t* phiT, uint16_t* gT, int nkp, trace_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Context aggregation / relation head                                       */

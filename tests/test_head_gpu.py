@@ -122,8 +122,8 @@ def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=
     """Shared checker: pair lists identical, logits rel-L2 < 2e-2, relation scores atol 2e-2, top-100 >= 99 %.
     dense_cut: with thousands of candidates and synthetic weights the scores around rank 100 are spaced
     ~3e-7 apart (relative 3e-4, far below bf16 resolution), so membership AT the cut is decided by rounding:
-    there the check is >= 95 % identical and every swapped triplet within the 2e-2 feature tolerance of the
-    oracle's 100th score."""
+    there the check is >= 95 % identical and every swapped triplet within twice the 2e-2 feature tolerance
+    of the oracle's 100th score."""
     from oracle.head_ref import head_forward
     from oracle.np_oracle import topk_triplets
     dbg = m._debug
@@ -151,7 +151,8 @@ def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=
             full = ref["prd_scores"].numpy() * (rs[ref["sbj_inds"]] * rs[ref["obj_inds"]])[:, None]
             cut = float(sc[-1])
             for (pp, kk) in (want - got) | (got - want):
-                assert abs(float(full[pp, kk]) - cut) <= 2e-2 * cut, (pp, kk, float(full[pp, kk]), cut)
+                # the swapped triplet's score and the cut both carry the 2e-2 tolerance
+                assert abs(float(full[pp, kk]) - cut) <= 2 * 2e-2 * cut, (pp, kk, float(full[pp, kk]), cut)
         poff += P
 
 

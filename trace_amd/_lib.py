@@ -35,6 +35,7 @@ SIGNATURES = {
     "trace_roi_align_fwd_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_nl_pool_split_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
+    "trace_nl_pool_split2_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
     "trace_rank_triplets_workspace_bytes": (c_size_t, [c_int, c_int]),
     "trace_rank_triplets": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
     "trace_act_cast_bf16": (c_int, [P, c_int, P, c_int, c_longlong, c_int, P, P]),

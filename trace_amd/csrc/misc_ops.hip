@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
 __global__ __launch_bounds__(256) void nl_pool_split_kernel(const uint16_t* __restrict__ tpg, int T, int H, int W,
                                                             int c, int nkv, int nkp,
                                                             uint16_t* __restrict__ phi_p,
-                                                            uint16_t* __restrict__ gT) {
+                                                            uint16_t* __restrict__ gT,
+                                                            uint16_t* __restrict__ phiT) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[64][72];
+  __shared__ __attribute__((aligned(16))) uint16_t tile2[64][72];   // phi^T (reassociated product only)
   const int n = blockIdx.z;
   const int p0 = blockIdx.x * 64, ch0 = blockIdx.y * 64;
   const int Ho = H >> 1, Wo = W >> 1, C3 = 3 * c;
@@ -147,7 +149,11 @@ __global__ __launch_bounds__(256) void nl_pool_split_kernel(const uint16_t* __re
           }
         }
     }
-    if (p < nkp) {
+    if (phiT) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tile2[g8 * 8 + j][pl] = f32_to_bf16(mphi[j]);
+    }
+    if (phi_p && p < nkp) {
       uint4 o;
       o.x = pack_bf16x2(mphi[0], mphi[1]);
       o.y = pack_bf16x2(mphi[2], mphi[3]);
@@ -162,9 +168,13 @@ __global__ __launch_bounds__(256) void nl_pool_split_kernel(const uint16_t* __re
   for (int item = threadIdx.x; item < 512; item += 256) {
     const int ch = item >> 3, pg = item & 7;
     const int p = p0 + pg * 8;
-    if (p < nkp)  // nkp % 8 == 0: a group of 8 key positions is inside or outside as a whole
+    if (p < nkp) {  // nkp % 8 == 0: a group of 8 key positions is inside or outside as a whole
       *reinterpret_cast<uint4*>(gT + ((long long)n * c + ch0 + ch) * nkp + p) =
           *reinterpret_cast<const uint4*>(&tile[ch][pg * 8]);
+      if (phiT)
+        *reinterpret_cast<uint4*>(phiT + ((long long)n * c + ch0 + ch) * nkp + p) =
+            *reinterpret_cast<const uint4*>(&tile2[ch][pg * 8]);
+    }
   }
 }
 
@@ -219,17 +229,24 @@ extern "C" int trace_transpose_bf16(const uint16_t* in, int batch, int rows, int
   return check_launch("transpose_bf16");
 }
 
-extern "C" int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c, uint16_t* phi_p,
-                                        uint16_t* gT, int nkp, trace_stream_t stream) {
+extern "C" int trace_nl_pool_split2_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c, uint16_t* phi_p,
+                                         uint16_t* phiT, uint16_t* gT, int nkp, trace_stream_t stream) {
   TRACE_REQUIRE(N >= 0 && T > 0 && H >= 2 && W >= 2 && c > 0, "nl_pool_split: bad shape");
   TRACE_REQUIRE(c % 64 == 0, "nl_pool_split: inter channels %d must be a multiple of 64", c);
   const int nkv = T * (H / 2) * (W / 2);
   TRACE_REQUIRE(nkp >= nkv && nkp % 8 == 0 && nkp < nkv + 8, "nl_pool_split: nkp must be nkv rounded up to 8");
   if (N == 0) return 0;
   TRACE_REQUIRE(N <= 65535, "nl_pool_split: batch too large");
-  TRACE_REQUIRE(tpg && phi_p && gT, "nl_pool_split: null pointer");
-  TRACE_REQUIRE((((uintptr_t)tpg | (uintptr_t)phi_p | (uintptr_t)gT) & 15) == 0, "nl_pool_split: pointers must be 16-byte aligned");
+  TRACE_REQUIRE(tpg && (phi_p || phiT) && gT, "nl_pool_split: null pointer");
+  TRACE_REQUIRE((((uintptr_t)tpg | (uintptr_t)phi_p | (uintptr_t)phiT | (uintptr_t)gT) & 15) == 0,
+                "nl_pool_split: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(nl_pool_split_kernel, dim3(ceil_div(nkp, 64), c / 64, N), dim3(256), 0, (hipStream_t)stream, tpg,
-                     T, H, W, c, nkv, nkp, phi_p, gT);
+                     T, H, W, c, nkv, nkp, phi_p, gT, phiT);
   return check_launch("nl_pool_split_bf16");
+}
+
+extern "C" int trace_nl_pool_split_bf16(const uint16_t* tpg, int N, int T, int H, int W, int c, uint16_t* phi_p,
+                                        uint16_t* gT, int nkp, trace_stream_t stream) {
+  TRACE_REQUIRE(N == 0 || phi_p, "nl_pool_split: null pointer");
+  return trace_nl_pool_split2_bf16(tpg, N, T, H, W, c, phi_p, nullptr, gT, nkp, stream);
 }

@@ -78,7 +78,7 @@ def _launch(name, fn, args, dev, flops=None):
         s.record()
         rc = fn(*args, stream)
         e.record()
-        IGEMM_TRACE.append((s, e, flops))
+        IGEMM_TRACE.append((s, e, flops, 0))
     else:
         rc = fn(*args, stream)
     if rc != 0:
@@ -106,7 +106,7 @@ class Plan:
                 s.record()
                 rc = fn(*args, stream)
                 e.record()
-                trace.append((s, e, flops))
+                trace.append((s, e, flops, 0))
             else:
                 rc = fn(*args, stream)
             if rc != 0:
@@ -144,8 +144,9 @@ def _keep(*tensors):
 class _span:
     """Brackets one igemm launch with events on the launch stream when IGEMM_TRACE is a list."""
 
-    def __init__(self, flops):
+    def __init__(self, flops, nbytes=0):
         self.flops = flops
+        self.nbytes = nbytes   # algorithmic bytes: every operand and the output once
 
     def __enter__(self):
         if IGEMM_TRACE is not None:
@@ -157,7 +158,7 @@ class _span:
     def __exit__(self, *a):
         if IGEMM_TRACE is not None:
             self.e.record()
-            IGEMM_TRACE.append((self.s, self.e, self.flops))
+            IGEMM_TRACE.append((self.s, self.e, self.flops, self.nbytes))
         return False
 
 
@@ -223,7 +224,8 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
     if bias is not None:
         bias = _f32(bias, "bias")
     ws = workspace(x.device)
-    with torch.cuda.device(x.device), _span(2.0 * out.numel() * kt * kh * kw * Cin):
+    nbytes = 2 * (x.numel() + w.numel()) + out.numel() * out.element_size() + (2 * out.numel() if residual is not None else 0)
+    with torch.cuda.device(x.device), _span(2.0 * out.numel() * kt * kh * kw * Cin, nbytes):
         L.check(L.lib().trace_conv3d_igemm_bf16(
             L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
             stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
@@ -242,7 +244,7 @@ def conv3d_stem(xp, w, bias, kt, kh, kwp, stride, out_thw, relu=True, alg_k=None
     out = torch.empty((N, To, Ho, Wo, Cout), dtype=torch.bfloat16, device=xp.device)
     if bias is not None:
         bias = _f32(bias, "bias")
-    with torch.cuda.device(xp.device), _span(2.0 * out.numel() * (alg_k or kt * kh * kwp * Cp)):
+    with torch.cuda.device(xp.device), _span(2.0 * out.numel() * (alg_k or kt * kh * kwp * Cp), 2 * (xp.numel() + w.numel() + out.numel())):
         L.check(L.lib().trace_conv3d_stem_bf16(L.ptr(xp), N, Tp, Hp, Wp, Cp, L.ptr(w), L.ptr(bias), Cout,
                                                kt, kh, kwp, stride[0], stride[1], stride[2], To, Ho, Wo,
                                                EPI_RELU if relu else 0, L.ptr(out), L.stream()),
@@ -337,7 +339,9 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
             raise RuntimeError("gemm_nt: out2 needs a contiguous output")
         c2 = torch.empty(out_shape, dtype=torch.bfloat16, device=A.device)
     ws = workspace(A.device)
-    with torch.cuda.device(A.device), _span(2.0 * b * M * N * K):
+    nbytes = (2 * (ba * M * K + bb * N * K) + out.numel() * out.element_size() + (2 * c2.numel() if c2 is not None else 0) +
+              (residual.numel() * residual.element_size() if residual is not None else 0))
+    with torch.cuda.device(A.device), _span(2.0 * b * M * N * K, nbytes):
         L.check(L.lib().trace_gemm_bf16_nt_ex(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
                                               L.ptr(bias), sBias, L.ptr(residual), epi, L.ptr(out), L.ptr(c2),
                                               _ACT[out2], L.ptr(ws), ws.numel(), L.stream()),
@@ -360,21 +364,23 @@ def transpose(x, pad_to=1):
     return out[0] if two_d else out
 
 
-def nl_pool_split(tpg, c):
+def nl_pool_split(tpg, c, transposed_phi=False):
     """tpg (N,T,H,W,3c) bf16 (theta|phi|g) -> phi_p (N,nkp,c), g^T (N,c,nkp): (1,2,2) max-pool of the phi / g
-    thirds in the operand layouts of the non-local block's two products; nkp = nkv rounded up to 8."""
+    thirds in the operand layouts of the non-local block's two products; nkp = nkv rounded up to 8.
+    transposed_phi: return phi^T (N,c,nkp) instead of phi_p (operands of the reassociated product phi^T g)."""
     tpg = _bf16(tpg, "tpg")
     N, T, H, W, C3 = tpg.shape
     if C3 != 3 * c:
         raise RuntimeError("nl_pool_split: last dim %d != 3*%d" % (C3, c))
     nkv = T * (H // 2) * (W // 2)
     nkp = (nkv + 7) // 8 * 8
-    phi_p = torch.empty((N, nkp, c), dtype=torch.bfloat16, device=tpg.device)
+    phi = torch.empty((N, c, nkp) if transposed_phi else (N, nkp, c), dtype=torch.bfloat16, device=tpg.device)
     gT = torch.empty((N, c, nkp), dtype=torch.bfloat16, device=tpg.device)
     with torch.cuda.device(tpg.device):
-        L.check(L.lib().trace_nl_pool_split_bf16(L.ptr(tpg), N, T, H, W, c, L.ptr(phi_p), L.ptr(gT), nkp, L.stream()),
+        L.check(L.lib().trace_nl_pool_split2_bf16(L.ptr(tpg), N, T, H, W, c, None if transposed_phi else L.ptr(phi),
+                                                  L.ptr(phi) if transposed_phi else None, L.ptr(gT), nkp, L.stream()),
                 "nl_pool_split")
-    return phi_p, gT, nkv
+    return phi, gT, nkv
 
 
 def roi_align_nhwc(x, rois, spatial_scale, pooled, sampling_ratio):
