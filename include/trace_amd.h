@@ -299,6 +299,18 @@ int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap,
                                uint16_t* s_map, uint16_t* o_map,
                                uint16_t* v_map, trace_stream_t stream);
 
+/* Pair attention + spatio_inferA/B in one pass - model_builder_rel.py:1524-1612 and :1039-1041
+ * (get_spatio_atten_feat, get_attention_mask_map, spatio_inferA / spatio_inferB, "+ V").  ROIAlign and the
+ * 1x1 convs are linear over the map, so  A(s_map) + B(o_map) = a_s ROIAlign(W_A V) + a_o ROIAlign(W_B V) + b  and
+ * q . ROIAlign(K) = ROIAlign(q . K):
+ *   vab (B,H,W,3D) bf16 = [V | W_A V | W_B V] per position;  qk (2*n_obj, ld_qk >= B*H*W) f32, row 2i = q_s of
+ *   object i against every position of every clip, row 2i+1 = q_o;  bias (D) f32 = b_A + b_B;
+ *   sp (P, PH*PW, D) bf16 = LeakyReLU(a_s VAp + a_o VBp + bias) + Vp, a = softmax over the cells.
+ * s_map / o_map / v_map are never written and the (P*PH*PW) x 2D x D GEMM of the reference's two convs is gone. */
+int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, const float* qk, int ld_qk,
+                           const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
+                           const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream);
+
 /* Tree-GRU message passing — lib/combine_tree/cluster_tree.py:163-204
  * (forward_v1), 281-316 (bottom-up), 318-330 (top-down, 'tree' mode), for a
  * forest of per-clip box trees and all feature groups in one launch.  The

@@ -123,6 +123,46 @@ def test_pair_attention_fused_vs_unfused():
     assert float((gv - vp).abs().max()) <= 1e-2 * float(vp.abs().max())
 
 
+def test_pair_infer_fused_vs_reference_order():
+    """One-pass pair attention + spatio_inferA/B (ops.pair_infer, [V | W_A V | W_B V] maps and q.K scalar maps)
+    vs the reference's order of operations in fp32: ROIAlign (pinned C oracle) of K / V on the union box,
+    softmax attention, the two 1x1 convs, LeakyReLU, + V (model_builder_rel.py:1596-1612, :1039-1040)."""
+    from trace_amd import ops
+    from oracle import c_oracle, np_oracle
+    rng = np.random.default_rng(7)
+    g = torch.Generator().manual_seed(7)
+    B, H, W, D, n = 2, 14, 14, 256, 8
+    kmap = torch.randn((B, H, W, D), generator=g).bfloat16()
+    vmap = torch.randn((B, H, W, D), generator=g)
+    wa = torch.randn((D, D), generator=g) / 16.0
+    wb = torch.randn((D, D), generator=g) / 16.0
+    bias = torch.randn((D,), generator=g) * 0.1
+    q = (torch.randn((2 * n, 2, D), generator=g) * 0.2).bfloat16()          # [object][s|o][D]
+    vab = torch.cat([vmap, vmap @ wa.t(), vmap @ wb.t()], -1).bfloat16()
+    rois, X, Y = [], [], []
+    for b in range(B):
+        r = np.concatenate([np.full((n, 1), b, np.float32), synth_boxes(rng, n)], 1)
+        s, o, rel = np_oracle.relpn_pairs(r)
+        rois.append(rel.astype(np.float32)); X.append(s + b * n); Y.append(o + b * n)
+    rel = np.concatenate(rois); X = np.concatenate(X); Y = np.concatenate(Y)
+    qk = ops.gemm_nt(q.view(4 * n, D).to(DEV), kmap.view(-1, D).to(DEV), out_f32=True)
+    sp = ops.pair_infer(vab.to(DEV), qk, torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV),
+                        torch.from_numpy(Y).int().to(DEV), bias.to(DEV), 1 / 16., 7)
+    kp = torch.from_numpy(c_oracle.roi_align_fwd(kmap.float().permute(0, 3, 1, 2).contiguous().numpy(), rel, 1 / 16., 7, 7, 0))
+    vp = torch.from_numpy(c_oracle.roi_align_fwd(vab[..., :D].float().permute(0, 3, 1, 2).contiguous().numpy(), rel, 1 / 16., 7, 7, 0))
+    P = rel.shape[0]
+    maps = []
+    for col, idx in ((0, X), (1, Y)):
+        score = (q[idx, col].float().view(P, D, 1, 1) * kp).sum(1).view(P, -1)
+        maps.append(vp * F.softmax(score, 1).view(P, 1, 7, 7))
+    ref = F.leaky_relu(F.conv2d(maps[0], wa.view(D, D, 1, 1)) + F.conv2d(maps[1], wb.view(D, D, 1, 1)) +
+                       bias.view(1, D, 1, 1), 0.1) + vp
+    got = sp.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
+    err = float((got - ref).norm() / ref.norm())
+    assert err < 2e-2, err
+    assert float((got - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("prd_k,topk", [(1, 100), (3, 100), (20, 50), (200, 7)])
 def test_rank_triplets_vs_oracle(prd_k, topk):
     """task_evaluation_vg_and_vrd.py:207-228 per clip (ragged clips, one with fewer candidates than topk)."""

@@ -203,6 +203,154 @@ __global__ __launch_bounds__(256) void pair_attention_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Pair attention + spatio_inferA/B in one pass (model_builder_rel.py:1524-1612, :1039-1041).
+// ROIAlign and the 1x1 convs are both linear over the feature map, so they commute:
+//   A(s_map) + B(o_map) = a_s (W_A Vp) + a_o (W_B Vp) + b_A + b_B,   W_A Vp = ROIAlign(W_A V-map)
+//   q_s . Kp[cell]      = ROIAlign of the scalar map  q_s . K-map
+// The caller supplies vab = [V | W_A V | W_B V] (B,H,W,3D) bf16 (one GEMM with host-folded weights) and
+// qk (2*n_obj, B*H*W) f32 = [q_s; q_o] K-map^T (row 2i = subject query of object i, 2i+1 = object query).
+// Per pair: phase 1 pools the two scalar maps on the union box -> softmax over the cells (a_s, a_o);
+// phase 2 pools the 3D channels (a lane owns 8 channels of V, W_A V and W_B V) and writes
+//   sp = LeakyReLU(a_s VAp + a_o VBp + bias) + Vp            (P, cells, D) bf16,
+// the operand of spatio_infer_fc.  Neither the pooled K-map nor s_map / o_map / v_map reach HBM, and the
+// (P*cells) x 2D x D GEMM of spatio_inferA|B disappears.
+// ---------------------------------------------------------------------------
+struct PSample {   // one bilinear sample of a cell: 4 corner offsets (elements of one map row) + weights
+  int pos[4];
+  float w[4];
+};
+
+__device__ __forceinline__ bool pa_sample(const PGeom& g, int PS, int H, int W, int ph, int pw, int iy, int ix, PSample& sm) {
+  float y = g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+  float x = g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return false;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  float yy = y, xx = x;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; yy = (float)y_low; } else { y_high = y_low + 1; }
+  if (x_low >= W - 1) { x_high = x_low = W - 1; xx = (float)x_low; } else { x_high = x_low + 1; }
+  const float ly = yy - (float)y_low, lx = xx - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+  sm.w[0] = hy * hx; sm.w[1] = hy * lx; sm.w[2] = ly * hx; sm.w[3] = ly * lx;
+  sm.pos[0] = y_low * W + x_low; sm.pos[1] = y_low * W + x_high;
+  sm.pos[2] = y_high * W + x_low; sm.pos[3] = y_high * W + x_high;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void pair_infer_kernel(
+    const uint16_t* __restrict__ vab, int B, int H, int W, int D, const float* __restrict__ qk, int ld_qk,
+    const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
+    const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
+  __shared__ float sc_s[PA_MAX_CELLS], sc_o[PA_MAX_CELLS];
+  const int p = blockIdx.x;
+  const int cells = PS * PS;
+  const int lpb = D >> 3;
+  const int bpr = 256 / lpb;
+  const int cg = threadIdx.x % lpb;
+  const int slot = threadIdx.x / lpb;
+
+  const float* r = rel_rois + (long long)p * 5;
+  PGeom g;
+  g.batch = min(max((int)r[0], 0), B - 1);
+  g.start_w = r[1] * scale;
+  g.start_h = r[2] * scale;
+  {
+    float end_w = r[3] * scale, end_h = r[4] * scale;
+    float roi_w = fmaxf(end_w - g.start_w, 1.0f), roi_h = fmaxf(end_h - g.start_h, 1.0f);
+    g.bin_h = roi_h / (float)PS;
+    g.bin_w = roi_w / (float)PS;
+    g.grid_h = (int)ceilf(roi_h / (float)PS);
+    g.grid_w = (int)ceilf(roi_w / (float)PS);
+  }
+  const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
+
+  // phase 1: pooled scores of the two scalar maps, one thread per cell (fixed summation order)
+  if (threadIdx.x < cells) {
+    const float* qs_row = qk + (long long)(2 * sbj[p]) * ld_qk + (long long)g.batch * H * W;
+    const float* qo_row = qk + (long long)(2 * obj[p] + 1) * ld_qk + (long long)g.batch * H * W;
+    const int cell = threadIdx.x;
+    const int ph = cell / PS, pw = cell - ph * PS;
+    float as = 0.f, ao = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy)
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        PSample sm;
+        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          as += sm.w[c] * qs_row[sm.pos[c]];
+          ao += sm.w[c] * qo_row[sm.pos[c]];
+        }
+      }
+    sc_s[cell] = as * inv_count;
+    sc_o[cell] = ao * inv_count;
+  }
+  __syncthreads();
+  float ms = -__builtin_inff(), mo = -__builtin_inff();
+  for (int c = 0; c < cells; ++c) {
+    ms = fmaxf(ms, sc_s[c]);
+    mo = fmaxf(mo, sc_o[c]);
+  }
+  float ss = 0.f, so = 0.f;
+  for (int c = 0; c < cells; ++c) {
+    ss += expf(sc_s[c] - ms);
+    so += expf(sc_o[c] - mo);
+  }
+  const float is = 1.0f / ss, io = 1.0f / so;
+
+  // phase 2: pool [V | W_A V | W_B V] and combine
+  const uint16_t* img = vab + (long long)g.batch * H * W * (3 * D) + cg * 8;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = bias[cg * 8 + j];
+  for (int cell0 = 0; cell0 < cells; cell0 += bpr) {
+    const int cell = cell0 + slot;
+    if (cell >= cells) break;
+    const int ph = cell / PS, pw = cell - ph * PS;
+    float va[8], aa[8], ba[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) va[j] = aa[j] = ba[j] = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy)
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        PSample sm;
+        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint16_t* px = img + (long long)sm.pos[c] * (3 * D);
+          const uint4 v0 = *reinterpret_cast<const uint4*>(px);
+          const uint4 v1 = *reinterpret_cast<const uint4*>(px + D);
+          const uint4 v2 = *reinterpret_cast<const uint4*>(px + 2 * D);
+          const uint32_t* u0 = &v0.x;
+          const uint32_t* u1 = &v1.x;
+          const uint32_t* u2 = &v2.x;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            va[2 * j] += sm.w[c] * __uint_as_float(u0[j] << 16);
+            va[2 * j + 1] += sm.w[c] * __uint_as_float(u0[j] & 0xffff0000u);
+            aa[2 * j] += sm.w[c] * __uint_as_float(u1[j] << 16);
+            aa[2 * j + 1] += sm.w[c] * __uint_as_float(u1[j] & 0xffff0000u);
+            ba[2 * j] += sm.w[c] * __uint_as_float(u2[j] << 16);
+            ba[2 * j + 1] += sm.w[c] * __uint_as_float(u2[j] & 0xffff0000u);
+          }
+        }
+      }
+    const float ws = expf(sc_s[cell] - ms) * is * inv_count, wo = expf(sc_o[cell] - mo) * io * inv_count;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = ws * aa[j] + wo * ba[j] + bv[j];       // A(s_map) + B(o_map)  (:1039)
+      t = t > 0.f ? t : 0.1f * t;                      // LeakyReLU(0.1)
+      o[j] = t + va[j] * inv_count;                    // + V  (:1040)
+    }
+    uint4 pk;
+    pk.x = pack_bf16x2(o[0], o[1]);
+    pk.y = pack_bf16x2(o[2], o[3]);
+    pk.z = pack_bf16x2(o[4], o[5]);
+    pk.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(sp + ((long long)p * cells + cell) * D + cg * 8) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Tree-GRU: one workgroup per (tree, feature group); levels are walked inside
 // the kernel (a tree is independent of every other tree), so the whole
 // bottom-up + top-down pass of all clips and groups is ONE launch.
@@ -706,6 +854,22 @@ extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* 
                      H, W, D, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_scale, pooled, so_stride, s_map,
                      o_map, v_map);
   return check_launch("pair_attention_fused");
+}
+
+extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, const float* qk, int ld_qk,
+                                      const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
+                                      const float* bias, float spatial_scale, int pooled, uint16_t* sp,
+                                      trace_stream_t stream) {
+  TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_infer: bad shape");
+  TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_infer: D=%d must be 64/128/256/512", D);
+  TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_infer: pooled=%d too large", pooled);
+  TRACE_REQUIRE(ld_qk >= B * H * W, "pair_infer: ld_qk=%d smaller than B*H*W", ld_qk);
+  if (P == 0) return 0;
+  TRACE_REQUIRE(vab && qk && rel_rois && sbj_inds && obj_inds && bias && sp, "pair_infer: null pointer");
+  TRACE_REQUIRE((((uintptr_t)vab | (uintptr_t)sp) & 15) == 0, "pair_infer: vab / sp must be 16-byte aligned");
+  hipLaunchKernelGGL(pair_infer_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, qk, ld_qk, rel_rois,
+                     sbj_inds, obj_inds, bias, spatial_scale, pooled, sp);
+  return check_launch("pair_infer_fused");
 }
 
 extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,

@@ -164,6 +164,9 @@ class Generalized_RCNN(nn.Module):
         self._pk_epoch = 0
         self._side_streams = {}
         self.side_stream = False
+        # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
+        # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
+        self.fuse_pair_infer = True
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -594,7 +597,23 @@ class Generalized_RCNN(nn.Module):
             # K / V maps of the pair attention (:287-289, :1545-1546)
             fm2 = fmap.view(-1, fmap.shape[-1])
             kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
-            vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+            if self.fuse_pair_infer:
+                # [V | W_A V | W_B V]: ROIAlign commutes with the 1x1 convs spatio_inferA / B (:1039), so they are
+                # applied to the 14x14 map once per clip instead of to every pair's pooled map
+                def make_vab():
+                    wv = self.spatio_atten_map.weight.detach().float().view(low, -1)
+                    bv = self.spatio_atten_map.bias.detach().float()
+                    wa = self.spatio_inferA[0].weight.detach().float().view(low, low)
+                    wb = self.spatio_inferB[0].weight.detach().float().view(low, low)
+                    w = torch.cat([wv, wa @ wv, wb @ wv], 0).to(torch.bfloat16).contiguous()
+                    b = torch.cat([bv, wa @ bv, wb @ bv], 0).contiguous()
+                    bab = (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous()
+                    return w, b, bab
+                w_vab, b_vab, bias_ab = self._cached("vab", make_vab)
+                vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
+                vmap = None
+            else:
+                vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
             # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
             # object Linears run as 2-batch GEMMs, the per-pair gathers + sums + frequency bias as one kernel
             w_se, b_se, _ = self._stack_w("sem_so_e", [self.sem_s_e[1], self.sem_o_e[1]])
@@ -654,17 +673,25 @@ class Generalized_RCNN(nn.Module):
         obj_score = F.softmax(self._gemm(obj_feature_relu, "cem_cls", [self.cem_Box_Outs.cls_score], out_f32=True), dim=1)
         # ---- target-adaptive pair attention (:1524-1612)
         lo = ops.act_cast(obj_feature, "leaky")
-        q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
-        q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
-        s_map, o_map, v_map, so = ops.pair_attention(kmap, vmap, union_d, dv[ix["X32"]], dv[ix["Y32"]], q_s, q_o,
-                                                     cfg.REL_SPATIAL_SCALE, ps)
         P = union_d.shape[0]
-        so = so.view(P * ps * ps, 2 * low)                                       # [s_map | o_map], written in place
-        wab, bab, _ = self._cached("inferAB", lambda: (
-            torch.cat([self.spatio_inferA[0].weight.detach().float().view(low, low),
-                       self.spatio_inferB[0].weight.detach().float().view(low, low)], 1).to(torch.bfloat16).contiguous(),
-            (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low))
-        sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
+        s_map = o_map = v_map = None
+        if self.fuse_pair_infer:
+            # [q_s | q_o] in one GEMM (bf16: the operand of the query x K-map product), rows viewed (2*Ntot, low)
+            q_so = self._gemm(lo, "att_so", [self.spatio_atten_s[1], self.spatio_atten_o[1]])
+            q_s, q_o = q_so[:, :low], q_so[:, low:]
+            qk = ops.gemm_nt(q_so.view(2 * Ntot, low), kmap.view(-1, low), out_f32=True)   # (2*Ntot, B*h*w)
+            sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps)
+        else:
+            q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
+            q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)
+            s_map, o_map, v_map, so = ops.pair_attention(kmap, vmap, union_d, dv[ix["X32"]], dv[ix["Y32"]], q_s, q_o,
+                                                         cfg.REL_SPATIAL_SCALE, ps)
+            so = so.view(P * ps * ps, 2 * low)                                   # [s_map | o_map], written in place
+            wab, bab, _ = self._cached("inferAB", lambda: (
+                torch.cat([self.spatio_inferA[0].weight.detach().float().view(low, low),
+                           self.spatio_inferB[0].weight.detach().float().view(low, low)], 1).to(torch.bfloat16).contiguous(),
+                (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low))
+            sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
         spatio_infer = self._gemm(sp.view(P, ps * ps * low), "sp_fc", [self.spatio_infer_fc[0]], (low, ps * ps), leaky=True)  # :1042 (+ leaky of :329)
         # ---- semantic branch (:1643-1668) and the sum of the four logit terms (:1066-1069, + freq bias :1075):
         # each Linear adds the running sum in its epilogue
@@ -687,7 +714,8 @@ class Generalized_RCNN(nn.Module):
                 top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
                                                  dv[ix["pclip"]], poff, dv[ix["poff"]][:-1], topk, prd_k)
         self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
-                           q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, spatio_infer=spatio_infer,
+                           q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, sp=sp.view(P, ps * ps, low),
+                           spatio_infer=spatio_infer,
                            logits=logits, node_obj=node_obj_d, node_reg=node_reg_d, tmaps=tmaps)
         return dict(det_labels=det_labels, det_scores=det_scores, sbj_labels=sbj_lab_all, obj_labels=obj_lab_all,
                     sbj_scores=sbj_sc_all, obj_scores=obj_sc_all, msp_det_scores=obj_score, prd_scores=prd, top=top)

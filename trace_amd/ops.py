@@ -452,6 +452,30 @@ def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_s
     return s_map, o_map, v, so
 
 
+def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7):
+    """vab (B,H,W,3D) bf16 = [V | W_A V | W_B V]; qk (2*n_obj, >= B*H*W) f32 (row 2i = q_s of object i, 2i+1 = q_o);
+    bias (D) f32 = b_A + b_B.  Returns sp (P, pooled*pooled, D) bf16 = LeakyReLU(A(s_map) + B(o_map)) + V
+    (model_builder_rel.py:1039-1040) without forming s_map / o_map."""
+    vab = _bf16(vab, "vab")
+    rel_rois, bias = _f32(rel_rois), _f32(bias)
+    L.require_gpu(sbj_inds, obj_inds, qk)
+    if qk.dtype != torch.float32 or qk.dim() != 2 or qk.stride(1) != 1:
+        raise RuntimeError("pair_infer: qk must be 2-D f32 with contiguous rows")
+    if sbj_inds.dtype != torch.int32 or obj_inds.dtype != torch.int32:
+        raise RuntimeError("pair_infer: indices must be int32")
+    B, H, W, D3 = vab.shape
+    D = D3 // 3
+    P = rel_rois.shape[0]
+    if qk.shape[1] < B * H * W or bias.numel() != D:
+        raise RuntimeError("pair_infer: qk / bias shape mismatch")
+    sp = torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=vab.device)
+    with torch.cuda.device(vab.device):
+        L.check(L.lib().trace_pair_infer_fused(L.ptr(vab), B, H, W, D, L.ptr(qk), qk.stride(0), L.ptr(rel_rois),
+                                               L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()), P, L.ptr(bias),
+                                               float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_infer")
+    return sp
+
+
 def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
     """x (n_nodes, n_groups*F) f32; forest = dict(tree_off, level_off, n_levels, parent, child_off,
     child_idx) of int32 device tensors; weights = list (per group) of dicts holding the 16 TRANSPOSED
