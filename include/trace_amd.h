@@ -170,6 +170,11 @@ int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
 #define TRACE_EPI_LEAKY 8    /* LeakyReLU(0.1) instead of ReLU               */
 #define TRACE_EPI_RES_POST 16 /* add `residual` AFTER the activation          */
 #define TRACE_EPI_RES_F32 32 /* `residual` is f32, not bf16 (trace_gemm_bf16_nt_ex) */
+#define TRACE_EPI_WTILED 64  /* trace_gemm_bf16_nt*: Bm is PRE-TILED for weight streaming (N % 128 == 0, K % 64 == 0,
+                              * ldb == K): block (n/128, k/64) is 16 KiB contiguous, holding for row r = n % 128 and
+                              * 16-byte chunk pc = 0..7 the 8 elements Bm[n][64*(k/64) + 8*(pc ^ (r & 7)) ..] at byte
+                              * offset r*128 + pc*16 (the kernel's LDS image), blocks ordered [n/128][k/64].  A K-step
+                              * then reads one contiguous block instead of 128 rows that lie K*2 bytes apart. */
 
 /* Conv3d + folded eval-mode BatchNorm3d (+residual)(+ReLU) as an implicit GEMM
  * on bf16 MFMA (mmcv ConvModule at resnet3d.py:250-283,549-557,721-730;

@@ -81,7 +81,8 @@ def test_conv3d_stem_matches_strided_conv():
 
 
 @pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024),
-                                   (96, 384, 16384), (20, 64, 4096)])  # last two: split-K path
+                                   (96, 384, 16384), (20, 64, 4096),      # split-K path
+                                   (160, 384, 32768), (50, 200, 32768)])  # weight-streaming shapes
 def test_gemm_nt(shape):
     from trace_amd import ops
     M, N, K = shape
@@ -94,6 +95,29 @@ def test_gemm_nt(shape):
     _close(out.cpu(), ref)
     out2 = ops.gemm_nt(A.to(DEV), B.to(DEV), bias=bias.to(DEV), alpha=0.5, relu=True)
     _close(out2.float().cpu(), torch.relu(ref))
+
+
+@pytest.mark.parametrize("shape", [(160, 384, 32768), (50, 256, 32768), (192, 128, 65536), (300, 256, 8192)])
+def test_gemm_nt_pretiled_weights_and_register_fed_kernel(shape):
+    """Weight-streaming paths: TRACE_EPI_WTILED (ops.tile_weights layout) and the register-fed kernel (tile id 10)
+    give the row-major result."""
+    from trace_amd import ops, _lib as L
+    M, N, K = shape
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn((M, K), generator=g).bfloat16().to(DEV)
+    B = (torch.randn((N, K), generator=g) / K ** 0.5).bfloat16().to(DEV)
+    bias = torch.randn((N,), generator=g).to(DEV)
+    ref = ops.gemm_nt(A, B, bias=bias, relu=True, out_f32=True)
+    got = ops.gemm_nt(A, ops.tile_weights(B), bias=bias, relu=True, out_f32=True, b_tiled=True)
+    _close(got.cpu(), ref.cpu())
+    L.lib().trace_igemm_tune(10, 0, 0)
+    try:
+        got2 = ops.gemm_nt(A, B, bias=bias, relu=True, out_f32=True)
+    finally:
+        L.lib().trace_igemm_tune(0, 0, 0)
+    _close(got2.cpu(), ref.cpu())
+    ref32 = torch.relu(A.float().cpu() @ B.float().cpu().t() + bias.cpu())
+    _close(got.cpu(), ref32)
 
 
 def test_gemm_nt_batched_and_transpose():

@@ -61,6 +61,8 @@ struct IgemmParams {
   uint16_t* out2;    // optional second output: bf16(act2(out value)), same rows / ldo as `out`
   int epi2;          // TRACE_EPI_RELU | TRACE_EPI_LEAKY applied to the second output only
   long long bs_bias; // blockIdx.z stride of `bias` (elements)
+  int xcd_slices;    // 1: split-K slices are pinned to XCDs (ksplit % 8 == 0), see igemm3_bf16_kernel
+  int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
 };
 
 constexpr int BK = 64;
@@ -95,12 +97,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // Epilogue shared by the main-loop variants: bias / residual / activation / (second output) / split-K slab.
 template <int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0, int pos0, int wm,
-                                               int wn, int fr, int fq) {
+                                               int wn, int fr, int fq, int kslice) {
   // lane holds, for position fr of fragment j and pair q: couts cbase + q*32 + fq*8 + [0..7]
   // (acc[2q][j] = first four, acc[2q+1][j] = last four)
   const int cbase = cout0 + wm * (16 * WM) + fq * 8;
   if (p.ksplit > 1) {
-    float* slab = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+    float* slab = p.partial + (long long)kslice * p.M * p.Cout;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
     nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
   }
 
-  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq);
+  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq, blockIdx.y);
 }
 
 
@@ -513,7 +515,16 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   int bid = blockIdx.x;
-  {
+  int kslice = blockIdx.y;
+  if (p.xcd_slices) {
+    // split-K with ksplit % 8 == 0: workgroups go to XCDs round-robin in dispatch order, so give XCD x the slices
+    // x, x+8, ... with ALL their tiles: the activation K-slice (not L2-resident as a whole: 32 MB for the 100352-wide
+    // FCs) is then fetched into ONE L2 and shared by every cout tile, instead of once per XCD
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = lin >> 3;
+    kslice = (lin & 7) + 8 * (q / (int)gridDim.x);
+    bid = q % (int)gridDim.x;
+  } else {
     const int nwg = gridDim.x;
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
@@ -531,7 +542,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   const int kseg = (lane & 7) ^ (lane >> 3);
 
   const int ksteps_all = (p.Ktot + BK - 1) / BK;
-  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ks_begin = kslice * p.ks_per;
   const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
   const int kbase = ks_begin * BK;           // uniform
   const int klin0 = kbase + kseg * 8;        // this lane's first K element
@@ -540,10 +551,22 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   const bool lane_tail = (ksteps_all - 1) * BK + kseg * 8 >= p.Ktot;
 
   const char* ap[WM];
+  int a_step = 2 * BK;     // bytes a weight pointer advances per K-step
+  if (p.w_tiled) {
+    // pre-tiled weights (TC == 128): K-step ks of cout tile tile_n is ONE contiguous 16 KiB block already in the
+    // swizzled LDS image order, so a wave instruction reads 1 KiB of consecutive addresses (DRAM-page friendly:
+    // the row-major layout touches 128 different weight rows, 200 KB apart, per K-step)
+    a_step = A_BYTES;
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
-    ap[i] = reinterpret_cast<const char*>(gw + (long long)row * p.ldw + klin0);
+    for (int i = 0; i < WM; ++i)
+      ap[i] = reinterpret_cast<const char*>(gw) + ((long long)tile_n * ksteps_all + ks_begin) * A_BYTES +
+              (i * 4 + wave) * 1024 + lane * 16;
+  } else {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
+      ap[i] = reinterpret_cast<const char*>(gw + (long long)row * p.ldw + klin0);
+    }
   }
   const char* bp[WN];
   long long boff[WN];      // conv: element offset of the receptive field's corner (+ this lane's k chunk)
@@ -639,7 +662,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       glds16(ap[i], a + i * 4096);
-      ap[i] += 2 * BK;
+      ap[i] += a_step;
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
@@ -712,7 +735,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     for (int st = 0; st < NST; ++st) step(st);
   }
   for (int st = 0; ks < ksteps; ++st) step(st);
-  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq);
+  igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq, kslice);
 }
 
 // Sum the split-K slabs in slice order (deterministic) and apply the epilogue.
@@ -785,6 +808,151 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight-streaming GEMM (the 100352-wide FC layers of the box / subject / object heads and fc_r,
+// fast_rcnn_heads.py:94-152, cluster_tree.py:369-372: a few hundred rois against 0.2 - 0.6 GB of weights).
+// HBM-bound on the weights, so the design is about bytes in flight, not MFMA rate:
+//   * 4 waves split the 128 couts of a workgroup (4 x 1 layout): a weight row is used by ONE wave, so
+//     weights bypass LDS - each lane loads its MFMA A-fragments straight from HBM with 16-byte loads,
+//     two K-steps ahead (3 register sets), 16 KB in flight per wave;
+//   * the activations (all M <= 192 positions, L2-resident) go through a 3-stage LDS-DMA ring shared by
+//     the four waves;
+//   * K is split over blockIdx.y; slices write f32 slabs, igemm_splitk_reduce_kernel sums them in order.
+// vmcnt bookkeeping: step s issues ONE group = {A fragments of step s+2, activation pieces of step s+2};
+// the wait before step s leaves the newest group in flight.
+// ---------------------------------------------------------------------------------------------
+template <int WN>
+__global__ __launch_bounds__(256) void wsgemm_bf16_kernel(const IgemmParams p) {
+  constexpr int TP = 16 * WN;           // positions held by the workgroup (>= M)
+  constexpr int NP = TP / 32;           // LDS-DMA pieces per thread per K-step
+  constexpr int STAGE = TP * 128;
+  constexpr int NSTB = 3;
+  constexpr int GROUP = 4 + NP;         // vector-memory instructions per issue group
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cout0 = blockIdx.x * 128 + wave * 32;
+  const int ksteps_all = p.Ktot / BK;
+  const int ks_begin = blockIdx.y * p.ks_per;
+  const int ksteps = min(ksteps_all - ks_begin, p.ks_per);
+  const long long kbase = (long long)ks_begin * BK;
+
+  // A fragments: lane (fr, fq) of fragment i holds weights[cout0 + 16 i + fr][k + 32 s + 8 fq .. +8]
+  const char* ap[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = min(cout0 + 16 * i + fr, p.Cout - 1);
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + kbase + fq * 8);
+  }
+  // activations: same loader as the igemm tiles (8 rows x 128 B per wave instruction, XOR-swizzled chunks)
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kseg = (lane & 7) ^ (lane >> 3);
+  const char* bp[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int m = min(lrow + 32 * i, p.M - 1);
+    bp[i] = reinterpret_cast<const char*>(p.in + (long long)m * p.pix + kbase + kseg * 8);
+  }
+  bf16x8 areg[3][2][2];   // [register set][fragment][K half]
+  auto issue = [&](int set, int stage) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      areg[set][i][0] = *reinterpret_cast<const bf16x8*>(ap[i]);
+      areg[set][i][1] = *reinterpret_cast<const bf16x8*>(ap[i] + 64);
+      ap[i] += 2 * BK;
+    }
+    char* b = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      glds16(bp[i], b + i * 4096);
+      bp[i] += 2 * BK;
+    }
+  };
+  f32x4 acc[2][WN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int boffs[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) boffs[s2] = lds_off(fr, s2 * 4 + fq);
+
+  int issued = 0, ks = 0;
+  if (0 < ksteps) { issue(0, 0); ++issued; }
+  if (1 < ksteps) { issue(1, 1); ++issued; }
+  auto step = [&](int st) {   // st = ks % 3: register set and LDS stage of this K-step (compile-time in the callers)
+    if (issued - ks - 1 >= 1) wait_vmcnt<GROUP>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (issued < ksteps) {
+      issue((st + 2) % 3, (st + 2) % 3);
+      ++issued;
+    }
+    const char* sb = smem + st * STAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(sb + boffs[s2] + j * (16 * 128));
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[st][0][s2], bfr, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(areg[st][1][s2], bfr, acc[1][j], 0, 0, 0);
+      }
+    }
+    ++ks;
+  };
+  for (; ks + 3 <= ksteps;) {
+    step(0);
+    step(1);
+    step(2);
+  }
+  if (ks < ksteps) step(0);
+  if (ks < ksteps) step(1);
+
+  // f32 slab of this K slice: lane holds couts cout0 + 16 i + 4 fq + [0..3] of position 16 j + fr
+  float* slab = p.partial + (long long)blockIdx.y * p.M * p.Cout;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int m = j * 16 + fr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = cout0 + 16 * i + 4 * fq;
+      if (c < p.Cout)
+        *reinterpret_cast<float4*>(slab + (long long)m * p.Cout + c) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
+template <int WN>
+static int launch_wsgemm(IgemmParams& p, hipStream_t s, int ksplit_req) {
+  const int ksteps = p.Ktot / BK;
+  const int tiles_n = ceil_div(p.Cout, 128);
+  long long ks = ksplit_req > 0 ? ksplit_req : (512 + tiles_n / 2) / tiles_n;
+  if (ks > ksteps / 16) ks = ksteps / 16;
+  if (ks > 32) ks = 32;
+  const long long cap_ws = (long long)(p.ws_bytes / ((size_t)p.M * p.Cout * sizeof(float)));
+  if (ks > cap_ws) ks = cap_ws;
+  if (ks < 1) return -1;   // no workspace for even one slab: the caller falls back to the tiled kernel
+  p.ks_per = ceil_div(ksteps, ks);
+  p.ksplit = ceil_div(ksteps, p.ks_per);
+  p.partial = (float*)p.ws;
+  constexpr int LDS = 3 * 16 * WN * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wsgemm_bf16_kernel<WN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((wsgemm_bf16_kernel<WN>), dim3(tiles_n, p.ksplit), dim3(256), LDS, s, p);
+  // the reduce kernel sums `ksplit` slabs (one included) and applies the epilogue
+  long long n4 = (long long)p.M * (p.Cout >> 2);
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+  return check_launch("wsgemm_bf16");
+}
+
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
   int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256,
@@ -826,6 +994,10 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
       if (TC + TP >= 256 && p.M <= 256 && ks < 21 && ksteps >= 1024) ks = 21;
       if (ks > ksteps / 16) ks = ksteps / 16;
       if (ks > 32) ks = 32;
+      // few cout tiles (<= 8: fc_r, 168 x 1024 x 100352, 90 -> 68 us): a multiple of 8 slices, pinned to XCDs (see the
+      // kernel) so that the activation K-slice is fetched into one L2 only; with many cout tiles (24 for the
+      // 3072-wide FC) an XCD already shares the slice between its tiles and whole rounds of workgroups matter more
+      if (ks >= 12 && nblk <= 8) ks = (ks + 4) / 8 * 8;
     } else if (nblk < 128 && ksteps >= 32) {
       // badly under-filled grids (single-clip convs): a few slices of >= 16 K-steps each
       ks = 256 / nblk;
@@ -840,6 +1012,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
       p.partial = (float*)p.ws;
     }
   }
+  p.xcd_slices = (p.ksplit >= 8 && p.ksplit % 8 == 0 && batch == 1) ? 1 : 0;
   const dim3 grid((unsigned)nblk, p.ksplit, batch);
   // ring depth.  v2 main loop: 2 stages (most workgroups per CU).  v3: the leaner K loop is latency-bound
   // when few workgroups share a CU, so the ring goes to 3 (4 for single-workgroup-per-CU grids) whenever
@@ -910,6 +1083,26 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
                 ? 1 : 0;
   const IgemmTune t = g_tune;
   int tile = t.tile;
+  if (p.w_tiled) {   // pre-tiled weights: 128-cout tiles of the v3 loop only
+    if (!p.dense || p.Cout % 128 != 0 || p.Ktot % BK != 0 || g_force_v2) {
+      set_error("gemm: TRACE_EPI_WTILED needs a dense problem with N %% 128 == 0 and K %% 64 == 0");
+      return 1;
+    }
+    if (tile != 3 && tile != 4 && tile != 8) tile = p.M <= 64 ? 3 : (p.M <= 128 || p.M > 192 ? 4 : 8);
+    switch (tile) {
+      case 3: return launch_cfg<4, 2>(p, batch, s, t.nst, t.ksplit);
+      case 8: return launch_cfg<4, 6>(p, batch, s, t.nst, t.ksplit);
+      default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
+    }
+  }
+  // register-fed weight-streaming kernel: selectable (tile id 10) but not the default - measured 198 us vs 182 us for the
+  // tiled loop on the 160 x 3072 x 100352 FC (both move the same bytes; the tiled loop with pre-tiled weights wins)
+  if (tile == 10 && p.dense && batch == 1 && p.ws && !p.narrow && p.M <= 192 && p.Ktot % BK == 0 &&
+      p.Ktot / BK >= 512 && p.Cout % 4 == 0) {
+    int rc = p.M <= 64 ? launch_wsgemm<4>(p, s, t.ksplit) : (p.M <= 128 ? launch_wsgemm<8>(p, s, t.ksplit) : launch_wsgemm<12>(p, s, t.ksplit));
+    if (rc >= 0) return rc;
+  }
+  if (tile == 10) tile = 0;
   if (!tile) {
     // Tile choice: keep >= ~2 workgroups per CU in flight when the problem allows.
     auto blocks = [&](int tc, int tp) { return (long long)ceil_div(p.Cout, tc) * ceil_div(p.M, tp) * batch; };
@@ -940,7 +1133,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
 using namespace trace;
 
 extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
-  TRACE_REQUIRE(tile >= 0 && tile <= 9 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
+  TRACE_REQUIRE(tile >= 0 && tile <= 10 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
   g_tune = IgemmTune{tile, nst, ksplit};
   return 0;
 }
@@ -1073,7 +1266,9 @@ static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K,
   p.ldo = ldc;
   p.bs_in = strideA; p.bs_w = strideB; p.bs_out = strideC;
   p.alpha = alpha;
-  p.epi = epilogue;
+  p.epi = epilogue & ~TRACE_EPI_WTILED;
+  p.w_tiled = (epilogue & TRACE_EPI_WTILED) ? 1 : 0;
+  TRACE_REQUIRE(!p.w_tiled || (batch == 1 && ldb == K), "gemm: TRACE_EPI_WTILED takes one dense pre-tiled weight matrix");
   // split-K partials are dense [M][N]: only for the plain (non-batched) case
   p.ws = (batch == 1 && !((uintptr_t)workspace & 15)) ? workspace : nullptr;
   p.ws_bytes = workspace_bytes;

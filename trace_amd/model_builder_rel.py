@@ -237,10 +237,20 @@ class Generalized_RCNN(nn.Module):
             return torch.stack(ws).to(torch.bfloat16).contiguous(), torch.stack(bs).contiguous(), layers[0].weight.shape[0]
         return self._cached(key, make)
 
-    def _gemm(self, x, key, layers, perm_hw_c=None, keep_pad=False, pad_bias=0.0, **kw):
+    def _gemm(self, x, key, layers, perm_hw_c=None, keep_pad=False, pad_bias=0.0, tiled=False, **kw):
         """x (M,K) -> (M,N) through the bf16 MFMA GEMM; pads K / slices N as needed (keep_pad: keep the
-        N-padding columns).  With out2=... returns (y, y2)."""
-        w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)
+        N-padding columns).  With out2=... returns (y, y2).  tiled: keep the packed weights in the pre-tiled
+        weight-streaming layout (ops.tile_weights) - the 100352-wide FCs."""
+        if tiled and (key + "/tiled") in self._pk:
+            w, b, n = self._pk[key + "/tiled"]
+            kw["b_tiled"] = True
+        else:
+            w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)
+            if tiled and w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0:
+                w = ops.tile_weights(w)
+                self._pk[key + "/tiled"] = (w, b, n)
+                del self._pk[key]                    # only the tiled copy stays resident
+                kw["b_tiled"] = True
         x = _bf(x)
         if x.shape[-1] != w.shape[1]:
             x = F.pad(x, (0, w.shape[1] - x.shape[-1]))
@@ -573,7 +583,8 @@ class Generalized_RCNN(nn.Module):
             # GEMM a second time as bf16 (with the consumer's ReLU / LeakyReLU applied): no cast / act launches
             pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
             pooled = pooled.view(Ntot, ps * ps * C)
-            h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True)
+            h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True,
+                            tiled=True)
             ori, ori_relu = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True, out2="relu")
             w_so, b_so, _ = self._stack_w("so_fc2", [self.S_Head.fc2, self.O_Head.fc2])
             det_so, det_so_bf = ops.gemm_nt(h1.view(Ntot, 3, D)[:, 1:].permute(1, 0, 2), w_so, bias=b_so, out_f32=True,
@@ -592,7 +603,7 @@ class Generalized_RCNN(nn.Module):
                                                residual=ori, out2="none")             # :945-946
             # regions (:222-245)
             reg_map = ops.roi_align_nhwc(fmap, dv[ix["reg"]], cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
-            r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True)
+            r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True, tiled=True)
             reg_feat, reg_feat_bf = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True, out2="none")
             # K / V maps of the pair attention (:287-289, :1545-1546)
             fm2 = fmap.view(-1, fmap.shape[-1])

@@ -288,8 +288,25 @@ EPI_RES_F32 = 32
 _ACT = {None: 0, "none": 0, "relu": EPI_RELU, "leaky": EPI_LEAKY}
 
 
+EPI_WTILED = 64
+
+
+def tile_weights(w):
+    """(N, K) bf16 row-major -> the pre-tiled layout of TRACE_EPI_WTILED (N % 128 == 0, K % 64 == 0): same
+    shape / bytes, blocks [N/128][K/64] of 128 rows x 64 k with the 16-byte chunks of row r stored at chunk
+    position pc holding logical chunk pc ^ (r & 7)."""
+    N, K = w.shape
+    if N % 128 or K % 64 or w.dtype != torch.bfloat16:
+        raise RuntimeError("tile_weights: needs bf16 (N % 128 == 0, K % 64 == 0)")
+    t = w.view(N // 128, 128, K // 64, 8, 8).permute(0, 2, 1, 3, 4)          # [nt][kt][r][chunk][8]
+    r = torch.arange(128, device=w.device).view(128, 1)
+    pc = torch.arange(8, device=w.device).view(1, 8)
+    src = (pc ^ (r & 7)).view(1, 1, 128, 8, 1).expand(N // 128, K // 64, 128, 8, 8)
+    return torch.gather(t, 3, src).contiguous().view(N, K)
+
+
 def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False, leaky=False,
-            residual_post=False, out=None, out2=None):
+            residual_post=False, out=None, out2=None, b_tiled=False):
     """C = alpha * A @ B^T (+bias)(+residual)(+ReLU | LeakyReLU(0.1))(+residual after the activation).
     A (M,K) or (b,M,K); B (N,K) or (b,N,K); row-strided views are accepted (last dim contiguous).
     `out` may be a row-strided view (e.g. a column slice of a wider zero-initialised buffer).
@@ -315,6 +332,10 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
     ldc = out.stride(-2)
     sC = out.stride(0) if out.dim() == 3 else 0
     epi = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_LEAKY if leaky else 0)
+    if b_tiled:
+        if B.dim() != 2 or not B.is_contiguous() or A.dim() != 2:
+            raise RuntimeError("gemm_nt: b_tiled takes one contiguous pre-tiled weight matrix (ops.tile_weights)")
+        epi |= EPI_WTILED
     if residual is not None:
         L.require_gpu(residual)
         if residual.dtype == torch.float32:
