@@ -395,8 +395,8 @@ int trace_rank_triplets(const float* prd, int P_total, int n_prd, int ld_prd, co
 /* Per-step host arrays (roi lists, forest CSR arrays, pair indices) read straight from PINNED host memory by
  * the first kernel of a captured step - replaces the reference's blocking per-list uploads
  * (lib/modeling_rel/model_builder_rel.py:1389, lib/combine_tree/cluster_tree.py:214,730: torch.from_numpy(..).cuda()).
- * `pinned` holds two slots of slot_bytes; launch number k (kept in the device word *counter, bumped by the
- * kernel) copies nbytes of slot k & 1 to dst, so the host fills the other slot while the previous step runs.
+ * `pinned` holds two slots of slot_bytes; launch number k (kept in the device word counter[0], bumped by the
+ * kernel; counter[1] is its arrival count: `counter` points at TWO zero-initialised words) copies nbytes of slot k & 1 to dst, so the host fills the other slot while the previous step runs.
  * Sizes multiples of 16, pointers 16-byte aligned; `pinned` must be device-accessible host memory. */
 int trace_upload_slots(const void* pinned, size_t slot_bytes, unsigned* counter, void* dst, size_t nbytes,
                        trace_stream_t stream);

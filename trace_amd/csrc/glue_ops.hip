@@ -173,16 +173,27 @@ extern "C" int trace_pair_assemble(const int64_t* det_labels, const float* det_s
 // blocking torch.from_numpy(..).cuda() per clip, lib/modeling_rel/model_builder_rel.py:1389,
 // lib/combine_tree/cluster_tree.py:214,730) straight from pinned host memory.  The pinned buffer holds
 // two slots; launch number k reads slot k & 1 (k lives in `counter`), so the host may fill the other
-// slot while the GPU still runs the previous step.  One workgroup: the counter is bumped after every
-// thread has read it.
+// slot while the GPU still runs the previous step.
 namespace trace {
-__global__ __launch_bounds__(1024) void upload_slots_kernel(const uint4* __restrict__ pinned, size_t slot_u4,
-                                                            unsigned* counter, uint4* __restrict__ dst, size_t n_u4) {
-  const unsigned seq = *counter;
-  const uint4* src = pinned + (size_t)(seq & 1u) * slot_u4;
-  for (size_t i = threadIdx.x; i < n_u4; i += blockDim.x) dst[i] = src[i];
+// counter[0] = launch number, counter[1] = workgroups of the current launch that have read it: the LAST one to
+// arrive bumps the launch number (every workgroup has its copy of `seq` by then) and clears the arrival count.
+__global__ __launch_bounds__(256) void upload_slots_kernel(const uint4* __restrict__ pinned, size_t slot_u4,
+                                                           unsigned* counter, uint4* __restrict__ dst, size_t n_u4) {
+  __shared__ unsigned s_seq;
+  if (threadIdx.x == 0) {
+    const unsigned seq = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_seq = seq;
+    __threadfence();   // the read of the launch number completes before this workgroup counts as arrived
+    const unsigned arrived = atomicAdd(counter + 1, 1u);
+    if (arrived == gridDim.x - 1) {
+      atomicExch(counter + 1, 0u);
+      atomicAdd(counter, 1u);
+    }
+  }
   __syncthreads();
-  if (threadIdx.x == 0) *counter = seq + 1u;
+  const uint4* src = pinned + (size_t)(s_seq & 1u) * slot_u4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_u4; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
 }
 }  // namespace trace
 
@@ -191,7 +202,11 @@ extern "C" int trace_upload_slots(const void* pinned, size_t slot_bytes, unsigne
   TRACE_REQUIRE(pinned && counter && dst, "upload_slots: null pointer");
   TRACE_REQUIRE(slot_bytes % 16 == 0 && nbytes % 16 == 0 && nbytes <= slot_bytes, "upload_slots: sizes must be multiples of 16, nbytes <= slot_bytes");
   TRACE_REQUIRE((((uintptr_t)pinned | (uintptr_t)dst) & 15) == 0, "upload_slots: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(trace::upload_slots_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint4*)pinned,
-                     slot_bytes / 16, counter, (uint4*)dst, nbytes / 16);
+  const size_t n_u4 = nbytes / 16;
+  unsigned blocks = (unsigned)((n_u4 + 255) / 256);
+  if (blocks > 32) blocks = 32;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(trace::upload_slots_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)pinned,
+                     slot_bytes / 16, counter, (uint4*)dst, n_u4);
   return trace::check_launch("upload_slots");
 }

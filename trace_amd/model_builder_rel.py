@@ -356,7 +356,7 @@ class Generalized_RCNN(nn.Module):
             # (ops.upload_slots): no copy-engine hop between two replays, and the host fills slot k+1 while
             # step k still runs
             pinned = torch.zeros((2 * nb,), dtype=torch.uint8, pin_memory=True)
-            counter = torch.zeros((1,), dtype=torch.int32, device=dev)
+            counter = torch.zeros((2,), dtype=torch.int32, device=dev)   # [launch number, arrival count]
             dv = prep["upl"].commit(dev, into=dv_buf[:max(prep["upl"].nbytes, 256)])
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))

@@ -562,10 +562,12 @@ def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off,
 
 def upload_slots(pinned, slot_bytes, counter, dst, nbytes):
     """First node of a captured step: dst[:nbytes] = slot (launch count & 1) of the two-slot PINNED host
-    buffer (see trace_upload_slots); `counter` is a 1-element int32 device tensor owned by the graph."""
+    buffer (see trace_upload_slots); `counter` is a zero-initialised 2-element int32 device tensor owned by the graph."""
     L.require_gpu(counter, dst)
     if pinned.is_cuda or not pinned.is_pinned():
         raise RuntimeError("upload_slots: `pinned` must be pinned host memory")
+    if counter.numel() < 2 or counter.dtype != torch.int32:
+        raise RuntimeError("upload_slots: counter must hold two int32 words")
     if pinned.numel() < 2 * slot_bytes or dst.numel() < nbytes:
         raise RuntimeError("upload_slots: buffers too small")
     with torch.cuda.device(dst.device):
