@@ -738,6 +738,149 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq, kslice);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem conv (3 -> 64, 5x7x7, spatial stride 2; lib/i3d/resnet3d.py:721-730) with the input patch resident in
+// LDS.  As an implicit GEMM through the generic loop the stem re-fetches every input pixel ~12 times and the
+// 143 KB weight matrix once per 128 positions (430 KB of L2 -> LDS traffic per 128 outputs: 205 us, operand
+// delivery bound).  Here a workgroup owns a 16 x 16 tile of output positions of one output frame:
+//   * its input patch (5 frames x 37 rows x 38 pixels x 4 channels bf16 = 56 KB) is loaded ONCE by LDS-DMA;
+//   * a (kt, kh) tap is one MFMA K-block (8 pixels x 4 channels = 32): the B fragment of output row j is a
+//     16-byte read at  lane_base + ((kt*37 + 2j + kh) * 304)  - one per-lane register plus immediates (the
+//     18 K-steps are fully unrolled); consecutive lanes read consecutive 16-byte chunks (conflict-free);
+//   * weights stream through a 3-stage LDS-DMA ring (8 KB per K-step) as in the generic loop;
+//   * 2 x 2 waves: wave (wm, wn) owns couts 32 wm .. +32 and output rows 8 wn .. +8 (8 fragments of 16 columns).
+// 199 KB of traffic per 256 outputs, 2 workgroups per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_KT = 5, ST_KH = 7;
+constexpr int ST_PR = 37;                 // patch rows  = 2*16 + 7 - 2
+constexpr int ST_PC = 19;                 // 16-byte chunks per patch row = (2*16 + 8 - 2) pixels * 8 B / 16
+constexpr int ST_ROWB = ST_PC * 16;       // 304
+constexpr int ST_CHUNKS = ST_KT * ST_PR * ST_PC;   // 3515
+constexpr int ST_PATCH = 14 * 256 * 16;    // 57344: the 14 load rounds of 256 lanes (the last round over-runs the patch with zeros)
+constexpr int ST_ASTAGE = 64 * 128;
+constexpr int ST_LDS = ST_PATCH + 3 * ST_ASTAGE;
+constexpr int ST_KSTEPS = (ST_KT * ST_KH + 1) / 2;  // 18 K-steps of two taps
+
+__global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  const int tiles_w = p.Wo >> 4, tiles_h = p.Ho >> 4;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w;
+  bid /= tiles_w;
+  const int th = bid % tiles_h;
+  bid /= tiles_h;
+  const int to = bid % p.To, n = bid / p.To;
+  const int r0 = th * 16, c0 = tw * 16;
+
+  // ---- patch: chunk q of the flattened (frame, row, 16-byte chunk) list -> LDS byte q*16
+  {
+    const long long row_b = (long long)p.Wi * 8, frame_b = (long long)p.Hi * row_b;
+    const char* src0 = reinterpret_cast<const char*>(p.in) +
+                       (((long long)n * p.Ti + (long long)to * p.st) * p.Hi + 2 * r0) * row_b + (long long)c0 * 16;
+#pragma unroll
+    for (int rd = 0; rd < (ST_CHUNKS + 255) / 256; ++rd) {
+      const int q = rd * 256 + tid;
+      const int f = q / (ST_PR * ST_PC);
+      const int rem = q - f * (ST_PR * ST_PC);
+      const int row = rem / ST_PC;
+      const int ch = rem - row * ST_PC;
+      const char* src = q < ST_CHUNKS ? src0 + f * frame_b + row * row_b + ch * 16 : zero;
+      glds16(src, smem + (rd * 256 + wave * 64) * 16);
+    }
+  }
+  // ---- weights ring
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kseg = (lane & 7) ^ (lane >> 3);
+  const char* ap[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)(lrow + 32 * i) * p.ldw + kseg * 8);
+  const bool tail_lane = (ST_KSTEPS - 1) * BK + kseg * 8 >= p.Ktot;   // past the last tap: zeros
+  auto issue_a = [&](int stage, bool last) {
+    char* a = smem + ST_PATCH + stage * ST_ASTAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16((last && tail_lane) ? zero : ap[i], a + i * 4096);
+      ap[i] += 2 * BK;
+    }
+  };
+  issue_a(0, false);
+  issue_a(1, false);
+
+  f32x4 acc[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int aoffs[2][2];
+#pragma unroll
+  for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = ST_PATCH + lds_off(wm * 32 + perm_row(odd, fr), s2 * 4 + fq);
+  const int lane_b = wn * (16 * ST_ROWB) + (fr + fq) * 16;
+
+#pragma unroll
+  for (int ks = 0; ks < ST_KSTEPS; ++ks) {
+    if (ks + 1 < ST_KSTEPS) wait_vmcnt<2>();   // the newest weight stage may stay in flight
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (ks + 2 < ST_KSTEPS) issue_a((ks + 2) % 3, ks + 2 == ST_KSTEPS - 1);
+    const int abase = (ks % 3) * ST_ASTAGE;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int tap = 2 * ks + s2;
+      if (tap >= ST_KT * ST_KH) break;
+      const int kt_i = tap / ST_KH, kh_i = tap % ST_KH;
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + abase + aoffs[0][s2]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + abase + aoffs[1][s2]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + lane_b + (kt_i * ST_PR + 2 * j + kh_i) * ST_ROWB);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- epilogue: lane holds couts 32 wm + 8 fq + [0..7] of position (row 8 wn + j, column fr)
+  const int cbase = wm * 32 + fq * 8;
+  float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + cbase);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + cbase + 4);
+    bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+    bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+  }
+  const bool relu = p.epi & TRACE_EPI_RELU;
+  uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const long long m = (((long long)n * p.To + to) * p.Ho + r0 + 8 * wn + j) * p.Wo + c0 + fr;
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = acc[0][j][r] + bv[r];
+      v[4 + r] = acc[1][j][r] + bv[4 + r];
+    }
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    uint4 ov;
+    ov.x = pack_bf16x2(v[0], v[1]);
+    ov.y = pack_bf16x2(v[2], v[3]);
+    ov.z = pack_bf16x2(v[4], v[5]);
+    ov.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(out + m * 64 + cbase) = ov;
+  }
+}
+
 // Sum the split-K slabs in slice order (deterministic) and apply the epilogue.
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmParams p) {
   const int cq = p.Cout >> 2;
@@ -1222,6 +1365,20 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
   p.alpha = 1.0f;
   p.epi = epilogue & ~TRACE_EPI_RESIDUAL;
   // the run must stay inside the padded row: checked above via (Wo-1)*sw+kwp <= Wp
+  if (kt == ST_KT && kh == ST_KH && kwp == 8 && Cp == 4 && Cout == 64 && sh == 2 && sw == 2 && Ho % 16 == 0 &&
+      Wo % 16 == 0 && !(epilogue & TRACE_EPI_OUT_F32) && !g_force_v2 && g_tune.tile == 0) {
+    // TRACE's stem shape: LDS-resident input patch (stem16_bf16_kernel); anything else takes the generic loop
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+      attr_done = true;
+    }
+    const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
+    TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem: grid too large");
+    hipLaunchKernelGGL(stem16_bf16_kernel, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+    return check_launch("conv3d_stem16");
+  }
   return launch_igemm(p, 1, (hipStream_t)stream);
 }
 
