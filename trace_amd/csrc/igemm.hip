@@ -96,8 +96,26 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 // Epilogue shared by the main-loop variants: bias / residual / activation / (second output) / split-K slab.
 template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0,
+                                                    const int (&mrow)[WN], int wm, int fq, int kslice);
+
+// positions of a tile are consecutive output rows: fragment j of wave column wn, lane fr -> row pos0 + ...
+template <int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0, int pos0, int wm,
                                                int wn, int fr, int fq, int kslice) {
+  int mrow[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
+    mrow[j] = m < p.M ? m : -1;
+  }
+  igemm_epilogue_rows<WM, WN>(p, acc, cout0, mrow, wm, fq, kslice);
+}
+
+// mrow[j]: output row (position) of this lane's column of fragment j, or -1 when it lies outside the problem
+template <int WM, int WN>
+__device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0,
+                                                    const int (&mrow)[WN], int wm, int fq, int kslice) {
   // lane holds, for position fr of fragment j and pair q: couts cbase + q*32 + fq*8 + [0..7]
   // (acc[2q][j] = first four, acc[2q+1][j] = last four)
   const int cbase = cout0 + wm * (16 * WM) + fq * 8;
@@ -105,8 +123,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
     float* slab = p.partial + (long long)kslice * p.M * p.Cout;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
-      if (m >= p.M) continue;
+      const int m = mrow[j];
+      if (m < 0) continue;
 #pragma unroll
       for (int q = 0; q < WM / 2; ++q) {
         const int c = cbase + q * 32;
@@ -134,9 +152,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f32x4 (&acc
   bool mok[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
-    const int m = pos0 + wn * (16 * WN) + j * 16 + fr;
-    mok[j] = m < p.M;
-    orow[j] = obase + (long long)min(m, p.M - 1) * p.ldo;
+    mok[j] = mrow[j] >= 0;
+    orow[j] = obase + (long long)max(mrow[j], 0) * p.ldo;
   }
   if (p.narrow) {
     // N or ldc not a multiple of 8 (plain GEMMs only): 4-channel groups, 8-byte accesses
@@ -1096,6 +1113,174 @@ static int launch_wsgemm(IgemmParams& p, hipStream_t s, int ksplit_req) {
   return check_launch("wsgemm_bf16");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Temporal 3x1x1 conv (stride 1, pad 1; conv1 of every inflated Bottleneck3d, lib/i3d/resnet3d.py:190-198,
+// 19 % of the backbone's MACs) with the input tile shared by the three taps.  Through the generic loop each
+// tap is its own K-step and reloads the (shifted) activation tile: 3 x (A + B) per 64 input channels.
+// Here a tile is ALL T frames x Q = 128/T spatial positions, ordered (t, q): the tap dt of position (t, q) is
+// LDS row (t + dt - 1) * Q + q, i.e. the same stage read Q rows lower / higher - an IMMEDIATE offset, and
+// Q % 8 == 0 keeps the XOR swizzle phase.  Q zero rows sit in front of and behind the 128 tile rows (t = -1
+// and t = T).  Per 64 input channels: one activation load + three weight loads (A through a 2-stage ring).
+// ---------------------------------------------------------------------------------------------
+template <int WM, int LOGQ>
+__global__ __launch_bounds__(256) void tconv3_bf16_kernel(const IgemmParams p) {
+  constexpr int WN = 4;
+  constexpr int TC = 32 * WM;
+  constexpr int Q = 1 << LOGQ;
+  constexpr int A_BYTES = TC * 128;
+  constexpr int B_BYTES = (128 + 2 * Q) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const bsm = smem;                   // 2 activation stages (one per 64-channel chunk)
+  char* const asm_ = smem + 2 * B_BYTES;    // 2 weight stages (one per K-step = (chunk, tap))
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;       // cout tile fastest: neighbours share the activation tile in L2
+  const int rest = bid / p.tiles_n;
+  const int tile_q = rest % p.tiles_m;
+  const int n = rest / p.tiles_m;
+  const int cout0 = tile_n * TC;
+  const int hw0 = tile_q * Q;
+  const int HW = p.Ho * p.Wo;
+  const int T = p.To;
+  const int Cin = p.Crun;
+
+  // zero rows: [0, Q) and [Q + 128, 2Q + 128) of both activation stages
+  for (int i = tid; i < 2 * 2 * Q * 8; i += 256) {
+    const int st = i / (2 * Q * 8), r2 = i % (2 * Q * 8);
+    const int row = r2 >> 3, ch = r2 & 7;
+    const int lrow2 = row < Q ? row : row + 128;
+    *reinterpret_cast<uint4*>(bsm + st * B_BYTES + lrow2 * 128 + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const int lrow = wave * 8 + (lane >> 3);
+  const int kseg = (lane & 7) ^ (lane >> 3);
+  const char* ap[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + kseg * 8);
+  }
+  const char* bp[WN];
+#pragma unroll
+  for (int i = 0; i < WN; ++i) {
+    const int pos = lrow + 32 * i;
+    const int t = pos >> LOGQ, hw = hw0 + (pos & (Q - 1));
+    bp[i] = hw < HW ? reinterpret_cast<const char*>(p.in + (((long long)n * T + t) * HW + hw) * p.pix + kseg * 8) : zero;
+  }
+  const long long a_tap = 2LL * Cin, a_chunk = 2LL * BK - 4LL * Cin;   // byte steps: next tap / first tap of the next chunk
+  const int nchunks = Cin / BK;
+  const int steps = 3 * nchunks;
+
+  auto issue_a = [&](int stage, int dt) {
+    char* a = asm_ + stage * A_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      glds16(ap[i], a + i * 4096);
+      ap[i] += dt == 2 ? a_chunk : a_tap;
+    }
+  };
+  auto issue_b = [&](int stage) {
+    char* b = bsm + stage * B_BYTES + Q * 128 + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WN; ++i) {
+      glds16(bp[i], b + i * 4096);
+      bp[i] += 2 * BK;
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int aoffs[2][2], boffs[2];
+#pragma unroll
+  for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = lds_off(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) boffs[s2] = lds_off(wn * 64 + fr, s2 * 4 + fq);
+
+  issue_b(0);
+  issue_a(0, 0);
+  int s = 0;
+  // k6 = s mod 6 (compile-time in the callers): tap k6 % 3, weight stage k6 & 1, activation stage (k6 / 3) & 1
+  auto step = [&](int k6) {
+    const int dt = k6 % 3;
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (s + 1 < steps) issue_a((k6 + 1) & 1, (k6 + 1) % 3);
+    if (dt == 0 && s + 3 < steps) issue_b(((k6 / 3) + 1) & 1);
+    const char* a = asm_ + (k6 & 1) * A_BYTES;
+    const char* b = bsm + ((k6 / 3) & 1) * B_BYTES + dt * (Q * 128);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 af[WM], bfr[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + aoffs[i & 1][s2] + (i >> 1) * (32 * 128));
+#pragma unroll
+      for (int j = 0; j < WN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(b + boffs[s2] + j * (16 * 128));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    ++s;
+  };
+  for (; s + 6 <= steps;) {
+    step(0); step(1); step(2); step(3); step(4); step(5);
+  }
+  if (s < steps) {   // an odd number of chunks: one more chunk on activation stage 0
+    step(0); step(1); step(2);
+  }
+
+  int mrow[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int pos = wn * 64 + j * 16 + fr;
+    const int t = pos >> LOGQ, hw = hw0 + (pos & (Q - 1));
+    mrow[j] = hw < HW ? (n * T + t) * HW + hw : -1;
+  }
+  igemm_epilogue_rows<WM, WN>(p, acc, cout0, mrow, wm, fq, 0);
+}
+
+template <int WM, int LOGQ>
+static int launch_tconv3(IgemmParams& p, int N, hipStream_t s) {
+  constexpr int TC = 32 * WM, Q = 1 << LOGQ;
+  constexpr int LDS = 2 * (128 + 2 * Q) * 128 + 2 * TC * 128;
+  p.tiles_n = ceil_div(p.Cout, TC);
+  p.tiles_m = ceil_div(p.Ho * p.Wo, Q);
+  p.ksplit = 1;
+  p.ks_per = 0;
+  const long long nwg = (long long)p.tiles_n * p.tiles_m * N;
+  if (nwg > 0x7fffffffLL) {
+    set_error("conv3d: grid too large");
+    return 1;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv3_bf16_kernel<WM, LOGQ>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((tconv3_bf16_kernel<WM, LOGQ>), dim3((unsigned)nwg), dim3(256), LDS, s, p);
+  return check_launch("conv3d_tconv3");
+}
+
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
   int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256,
@@ -1106,6 +1291,8 @@ struct IgemmTune {
 static thread_local IgemmTune g_tune = {0, 0, 0};
 // TRACE_IGEMM_V2=1 keeps the v2 main loop (A/B measurements)
 static const bool g_force_v2 = getenv("TRACE_IGEMM_V2") != nullptr;
+// TRACE_NO_TCONV=1 sends temporal convs through the generic loop (A/B measurements)
+static const bool g_no_tconv = getenv("TRACE_NO_TCONV") != nullptr;
 
 template <int WM, int WN>
 static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int ksplit_req) {
@@ -1226,6 +1413,22 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
                 ? 1 : 0;
   const IgemmTune t = g_tune;
   int tile = t.tile;
+  // temporal 3x1x1 convs: the tile spans all T frames and is shared by the three taps (tconv3_bf16_kernel)
+  if (!tile && !g_force_v2 && !g_no_tconv && batch == 1 && !p.narrow && p.kt == 3 && p.kh == 1 && p.kw == 1 && p.st == 1 && p.sh == 1 &&
+      p.sw == 1 && p.pt == 1 && p.ph == 0 && p.pw == 0 && p.dt == 1 && p.Crun % BK == 0 && p.Crun <= 2048 &&
+      (p.To == 2 || p.To == 4 || p.To == 8) && p.Ti == p.To && p.M < 0x40000000) {
+    const int N = p.M / (p.To * p.Ho * p.Wo);
+    const int Q = 128 / p.To;
+    const long long wg4 = (long long)ceil_div(p.Cout, 128) * ceil_div(p.Ho * p.Wo, Q) * N;
+    const bool small = p.Cout <= 64 || wg4 < 384;    // 64-cout tiles when 128-cout tiles cannot fill the chip
+    const long long wg = small ? (long long)ceil_div(p.Cout, 64) * ceil_div(p.Ho * p.Wo, Q) * N : wg4;
+    if (wg >= 300)   // measured: below ~1 workgroup per CU the generic loop's deeper ring wins (1024->256 @ 4x14x14)
+    switch (p.To) {
+      case 8: return small ? launch_tconv3<2, 4>(p, N, s) : launch_tconv3<4, 4>(p, N, s);
+      case 4: return small ? launch_tconv3<2, 5>(p, N, s) : launch_tconv3<4, 5>(p, N, s);
+      default: return small ? launch_tconv3<2, 6>(p, N, s) : launch_tconv3<4, 6>(p, N, s);
+    }
+  }
   if (p.w_tiled) {   // pre-tiled weights: 128-cout tiles of the v3 loop only
     if (!p.dense || p.Cout % 128 != 0 || p.Ktot % BK != 0 || g_force_v2) {
       set_error("gemm: TRACE_EPI_WTILED needs a dense problem with N %% 128 == 0 and K %% 64 == 0");
