@@ -130,14 +130,18 @@ def test_step_graph_replay_equals_eager(setup):
         eager.append([{k: o[k].clone() for k in keys} for o in outs])
     m.graph_step = True
     try:
-        for rep in range(2):
-            for (fr, bl, fe, ro), want in zip(cases, eager):
-                outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
-                for o, w in zip(outs, want):
-                    for k in keys:
-                        assert torch.equal(o[k], w[k]), (rep, k)
+        for side in (False, True):       # True: the weight-streaming branch forked onto a second stream inside the graph
+            m.side_stream = side
+            m._step_graphs.clear()
+            for rep in range(2):
+                for (fr, bl, fe, ro), want in zip(cases, eager):
+                    outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+                    for o, w in zip(outs, want):
+                        for k in keys:
+                            assert torch.equal(o[k], w[k]), (side, rep, k)
     finally:
         m.graph_step = False
+        m.side_stream = False
 
 
 def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=False, **okw):

@@ -164,6 +164,7 @@ class Generalized_RCNN(nn.Module):
         self._pk_epoch = 0
         self._side_streams = {}
         self.side_stream = False
+        self.side_fork_stage = 1      # fork after layer2 (0-based residual stage index; -1 = after the stem)
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
@@ -567,76 +568,101 @@ class Generalized_RCNN(nn.Module):
         X, Y, LCA, union_d = dv[ix["X"]], dv[ix["Y"]], dv[ix["LCA"]], dv[ix["union"]]
         E = cfg.OBJ_EMBED_DIM
 
-        # ---- everything that does not read the temporal maps.  With `side_stream` it is forked onto a
-        # second stream next to the backbone and joined before the temporal branches; measured on MI355X
-        # this LOSES 10 % inside the captured step graph (1604 -> 1457 clips/s: the branch costs more in
-        # graph-node synchronisation than the overlap returns), so it stays off by default.
+        # ---- everything that does not read the temporal maps runs as `part_a`; with `side_stream` on a second
+        # stream beside the backbone (measured inside the captured step graph: 3.00 -> 2.93 ms per step, the same
+        # for every fork point between the stem and layer3; an early version of the head lost 10 % this way)
         main = torch.cuda.current_stream(dev)
         side = main
         if self.side_stream:
             side = self._side_streams.get(dev.index)
             if side is None:
                 side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
-            side.wait_stream(main)
-        with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
-            # detection heads (:742-743, :938-952).  f32 values that feed a Linear come out of the producing
-            # GEMM a second time as bf16 (with the consumer's ReLU / LeakyReLU applied): no cast / act launches
-            pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
-            pooled = pooled.view(Ntot, ps * ps * C)
-            h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True,
-                            tiled=True)
-            ori, ori_relu = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True, out2="relu")
-            w_so, b_so, _ = self._stack_w("so_fc2", [self.S_Head.fc2, self.O_Head.fc2])
-            det_so, det_so_bf = ops.gemm_nt(h1.view(Ntot, 3, D)[:, 1:].permute(1, 0, 2), w_so, bias=b_so, out_f32=True,
-                                            relu=not cfg.NO_FC7_RELU, out2="none")      # S_Head | O_Head fc2, one launch
-            # class scores: the N-padding columns get a -1e30 bias, so the softmax over the padded row is exact
-            cls_pad = F.softmax(self._gemm(ori_relu, "cls", [self.Box_Outs.cls_score], out_f32=True, keep_pad=True,
-                                           pad_bias=-1e30), dim=1)
-            cls = cls_pad[:, :cfg.NUM_CLASSES]
-            if "lab" in ix:                                                          # labels / scores came with the boxes (:895-898)
-                det_labels, det_scores = dv[ix["lab"]], dv[ix["sc"]]
-            else:
-                det_scores, det_labels = cls[:, 1:].max(dim=1)                       # :903-904
-                det_labels = det_labels + 1
-            emb = self._gemm(ops.act_cast(cls_pad), "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], leaky=True)
-            det_feat, det_feat_bf = self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True,
-                                               residual=ori, out2="none")             # :945-946
-            # regions (:222-245)
-            reg_map = ops.roi_align_nhwc(fmap, dv[ix["reg"]], cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
-            r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True, tiled=True)
-            reg_feat, reg_feat_bf = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True, out2="none")
-            # K / V maps of the pair attention (:287-289, :1545-1546)
-            fm2 = fmap.view(-1, fmap.shape[-1])
-            kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
-            if self.fuse_pair_infer:
-                # [V | W_A V | W_B V]: ROIAlign commutes with the 1x1 convs spatio_inferA / B (:1039), so they are
-                # applied to the 14x14 map once per clip instead of to every pair's pooled map
-                def make_vab():
-                    wv = self.spatio_atten_map.weight.detach().float().view(low, -1)
-                    bv = self.spatio_atten_map.bias.detach().float()
-                    wa = self.spatio_inferA[0].weight.detach().float().view(low, low)
-                    wb = self.spatio_inferB[0].weight.detach().float().view(low, low)
-                    w = torch.cat([wv, wa @ wv, wb @ wv], 0).to(torch.bfloat16).contiguous()
-                    b = torch.cat([bv, wa @ bv, wb @ bv], 0).contiguous()
-                    bab = (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous()
-                    return w, b, bab
-                w_vab, b_vab, bias_ab = self._cached("vab", make_vab)
-                vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
-                vmap = None
-            else:
-                vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
-            # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
-            # object Linears run as 2-batch GEMMs, the per-pair gathers + sums + frequency bias as one kernel
-            w_se, b_se, _ = self._stack_w("sem_so_e", [self.sem_s_e[1], self.sem_o_e[1]])
-            lows = ops.gemm_nt(emb.view(Ntot, 3, E)[:, 1:].permute(1, 0, 2), w_se, bias=b_se, out_f32=True)
-            w_sm, b_sm, n_rel = self._stack_w("sem_so", [self.sem_s[0], self.sem_o[0]])
-            parts = ops.gemm_nt(det_so_bf, w_sm, bias=b_sm, out_f32=True)            # (2, Ntot, n_rel padded)
-            freq = self.freq_bias.rel_baseline.weight.detach() if cfg.USE_FREQ_BIAS else None    # :1064,:1075
-            sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all, so_bias, so_part = ops.pair_assemble(
-                det_labels, det_scores, X, Y, lows[0], lows[1], parts[0], parts[1], freq, n_rel, cfg.NUM_CLASSES - 1)
+        pa = {}
+
+        def part_a():
+            """Everything that does not read the temporal maps (detection heads, region FC, K / V maps, semantic
+            inputs).  With `side_stream` it is forked onto a second stream once residual stage `side_fork_stage` of
+            the backbone has been launched, and joined before the temporal branches: the HBM-bound weight-streaming
+            FCs then overlap the L2- / latency-bound late backbone stages."""
+            if self.side_stream:
+                side.wait_stream(main)
+            with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
+                # detection heads (:742-743, :938-952).  f32 values that feed a Linear come out of the producing
+                # GEMM a second time as bf16 (with the consumer's ReLU / LeakyReLU applied): no cast / act launches
+                pooled = ops.roi_align_nhwc(blob, det_all_d, cfg.CONV_BODY_SCALE, ps, cfg.ROI_XFORM_SAMPLING_RATIO)
+                pooled = pooled.view(Ntot, ps * ps * C)
+                h1 = self._gemm(pooled, "fc1_bso", [self.Box_Head.fc1, self.S_Head.fc1, self.O_Head.fc1], (C, ps * ps), relu=True,
+                                tiled=True)
+                ori, ori_relu = self._gemm(h1[:, :D], "box_fc2", [self.Box_Head.fc2], out_f32=True, out2="relu")
+                w_so, b_so, _ = self._stack_w("so_fc2", [self.S_Head.fc2, self.O_Head.fc2])
+                det_so, det_so_bf = ops.gemm_nt(h1.view(Ntot, 3, D)[:, 1:].permute(1, 0, 2), w_so, bias=b_so, out_f32=True,
+                                                relu=not cfg.NO_FC7_RELU, out2="none")      # S_Head | O_Head fc2, one launch
+                # class scores: the N-padding columns get a -1e30 bias, so the softmax over the padded row is exact
+                cls_pad = F.softmax(self._gemm(ori_relu, "cls", [self.Box_Outs.cls_score], out_f32=True, keep_pad=True,
+                                               pad_bias=-1e30), dim=1)
+                cls = cls_pad[:, :cfg.NUM_CLASSES]
+                if "lab" in ix:                                                          # labels / scores came with the boxes (:895-898)
+                    det_labels, det_scores = dv[ix["lab"]], dv[ix["sc"]]
+                else:
+                    det_scores, det_labels = cls[:, 1:].max(dim=1)                       # :903-904
+                    det_labels = det_labels + 1
+                emb = self._gemm(ops.act_cast(cls_pad), "embeds", [self.embed_obj_det, self.embed_s, self.embed_o], leaky=True)
+                det_feat, det_feat_bf = self._gemm(emb[:, :E], "after_emb", [self.after_obj_det_embed[1]], out_f32=True,
+                                                   residual=ori, out2="none")             # :945-946
+                # regions (:222-245)
+                reg_map = ops.roi_align_nhwc(fmap, dv[ix["reg"]], cfg.REL_SPATIAL_SCALE, ps, 0).view(Mtot, ps * ps * C)
+                r1 = self._gemm(reg_map, "fc_r0", [ct3.fc_r[0]], (C, ps * ps), relu=True, tiled=True)
+                reg_feat, reg_feat_bf = self._gemm(r1, "fc_r2", [ct3.fc_r[2]], out_f32=True, out2="none")
+                # K / V maps of the pair attention (:287-289, :1545-1546)
+                fm2 = fmap.view(-1, fmap.shape[-1])
+                kmap = self._gemm(fm2, "kmap", [self.atten_q_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+                if self.fuse_pair_infer:
+                    # [V | W_A V | W_B V]: ROIAlign commutes with the 1x1 convs spatio_inferA / B (:1039), so they are
+                    # applied to the 14x14 map once per clip instead of to every pair's pooled map
+                    def make_vab():
+                        wv = self.spatio_atten_map.weight.detach().float().view(low, -1)
+                        bv = self.spatio_atten_map.bias.detach().float()
+                        wa = self.spatio_inferA[0].weight.detach().float().view(low, low)
+                        wb = self.spatio_inferB[0].weight.detach().float().view(low, low)
+                        w = torch.cat([wv, wa @ wv, wb @ wv], 0).to(torch.bfloat16).contiguous()
+                        b = torch.cat([bv, wa @ bv, wb @ bv], 0).contiguous()
+                        bab = (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous()
+                        return w, b, bab
+                    w_vab, b_vab, bias_ab = self._cached("vab", make_vab)
+                    vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
+                    vmap = None
+                else:
+                    vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
+                # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
+                # object Linears run as 2-batch GEMMs, the per-pair gathers + sums + frequency bias as one kernel
+                w_se, b_se, _ = self._stack_w("sem_so_e", [self.sem_s_e[1], self.sem_o_e[1]])
+                lows = ops.gemm_nt(emb.view(Ntot, 3, E)[:, 1:].permute(1, 0, 2), w_se, bias=b_se, out_f32=True)
+                w_sm, b_sm, n_rel = self._stack_w("sem_so", [self.sem_s[0], self.sem_o[0]])
+                parts = ops.gemm_nt(det_so_bf, w_sm, bias=b_sm, out_f32=True)            # (2, Ntot, n_rel padded)
+                freq = self.freq_bias.rel_baseline.weight.detach() if cfg.USE_FREQ_BIAS else None    # :1064,:1075
+                sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all, so_bias, so_part = ops.pair_assemble(
+                    det_labels, det_scores, X, Y, lows[0], lows[1], parts[0], parts[1], freq, n_rel, cfg.NUM_CLASSES - 1)
+                pa.update(det_labels=det_labels, det_scores=det_scores, det_feat=det_feat, det_feat_bf=det_feat_bf,
+                          reg_feat=reg_feat, reg_feat_bf=reg_feat_bf, kmap=kmap, vmap=vmap,
+                          vab=vab if self.fuse_pair_infer else None, bias_ab=bias_ab if self.fuse_pair_infer else None,
+                          sbj_lab_all=sbj_lab_all, obj_lab_all=obj_lab_all, sbj_sc_all=sbj_sc_all, obj_sc_all=obj_sc_all,
+                          so_bias=so_bias, so_part=so_part, n_rel=n_rel)
+
         # ---- I3D backbone (:978-981)
-        i3d = self.Prd_RCNN.forward_ndhwc_graphed if graph_backbone else self.Prd_RCNN.forward_ndhwc
-        tmaps = i3d(all_frames, in_ntchw=True)                                  # (B,T',h,w,2048) bf16
+        hook = None
+        if self.side_stream and not graph_backbone:
+            hook = (self.side_fork_stage, part_a)
+        else:
+            part_a()
+        if graph_backbone:
+            tmaps = self.Prd_RCNN.forward_ndhwc_graphed(all_frames, in_ntchw=True)
+        else:
+            tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True, stage_hook=hook)   # (B,T',h,w,2048) bf16
+        det_labels, det_scores, det_feat, det_feat_bf = pa["det_labels"], pa["det_scores"], pa["det_feat"], pa["det_feat_bf"]
+        reg_feat, reg_feat_bf, kmap, vmap, vab, bias_ab = (pa["reg_feat"], pa["reg_feat_bf"], pa["kmap"], pa["vmap"],
+                                                           pa["vab"], pa["bias_ab"])
+        sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all = pa["sbj_lab_all"], pa["obj_lab_all"], pa["sbj_sc_all"], pa["obj_sc_all"]
+        so_bias, so_part, n_rel = pa["so_bias"], pa["so_part"], pa["n_rel"]
         Tn = tmaps.shape[1]
         if Tn != prep["Tn"]:
             raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))

@@ -351,17 +351,24 @@ class ResNet3d(nn.Module):
                             alg_k=kt * kh * kw * C)
         return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
-    def forward_ndhwc(self, x, in_ntchw=False):
-        """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw) -> channels-last bf16 (N,T',H',W',feat_dim)."""
+    def forward_ndhwc(self, x, in_ntchw=False, stage_hook=None):
+        """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw) -> channels-last bf16 (N,T',H',W',feat_dim).
+        stage_hook: optional (stage_index, callable): the callable runs right after residual stage `stage_index`
+        (0-based; -1 = after the stem) has been launched - the relation head forks its weight-streaming branch
+        onto a second stream there."""
         if self.training:
             raise NotImplementedError("trace_amd.ResNet3d implements the inference path; call .eval()")
         with torch.no_grad():
             x = self._run_stem(x, in_ntchw)
+            if stage_hook is not None and stage_hook[0] == -1:
+                stage_hook[1]()
             for i, name in enumerate(self.res_layers[:self.num_stages]):
                 for blk in getattr(self, name):
                     x = blk.run(x)
                 if i == 0 and self.with_pool2:
                     x = ops.maxpool3d(x, (2, 1, 1), (2, 1, 1))
+                if stage_hook is not None and stage_hook[0] == i:
+                    stage_hook[1]()
         return x
 
     def out_frames(self, T):
