@@ -683,16 +683,22 @@ class Generalized_RCNN(nn.Module):
             # cur_feat + value MLP (:201, :305); second output = the ReLU'd operand of o2c / r2c (:374-379)
             return self._gemm(v, tag + "_v3", [val[3]], out_f32=True, residual=cur_feat, out2="relu")
 
+        if self.side_stream:
+            side.wait_stream(main)
+        with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
+            reg_agg, reg_agg_relu = temporal_branch(dv[ix["t_reg"]], reg_feat, reg_feat_bf, ct3.temporal_r_fc,
+                                                    ct3.temporal_r_atten_q_s, ct3.temporal_r_atten_q_o,
+                                                    ct3.temporal_r_feat_val, "treg")
+            r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
         obj_agg, obj_agg_relu = temporal_branch(dv[ix["t_obj"]], det_feat, det_feat_bf, ct3.temporal_obj_fc,
                                                 ct3.temporal_obj_atten_q_s, ct3.temporal_obj_atten_q_o,
                                                 ct3.temporal_obj_feat_val, "tobj")
-        # ---- temporal region features (:268-305)
-        reg_agg, reg_agg_relu = temporal_branch(dv[ix["t_reg"]], reg_feat, reg_feat_bf, ct3.temporal_r_fc,
-                                                ct3.temporal_r_atten_q_s, ct3.temporal_r_atten_q_o,
-                                                ct3.temporal_r_feat_val, "treg")
-        # ---- tree message passing (:307-330)
         o2c = self._gemm(obj_agg_relu, "o2c", [ct3.o2c[1]], out_f32=True)
-        r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
+        # ---- temporal region features (:268-305): independent of the object branch (a chain of small,
+        # latency-bound launches), so with `side_stream` the two chains run side by side
+        if self.side_stream:
+            main.wait_stream(side)
+        # ---- tree message passing (:307-330)
         fc = ct3.feat_combine
         G = ct3.group_coeffi
         gw = fc // G
