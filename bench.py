@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--objects", type=int, default=20)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="captured step graphs in flight per GPU (2 measured no faster than 1: 2634 vs 2653 clips/s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch events (roofline leg)")
     return ap.parse_args()
@@ -96,6 +98,7 @@ def main():
     model.to(dev)
     model.graph_step = True     # serving mode: the whole step replays from one HIP graph per step signature
     model.side_stream = True    # the HBM-bound weight-streaming FCs run on a second stream beside the backbone (-2 %)
+    model.pipeline = args.pipeline   # step graphs in flight (2: the head of step i overlaps the backbone of step i+1)
     calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
     model.Prd_RCNN.calibrate_bn(calib.to(dev))       # setup only: sane activations for random weights
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -107,14 +110,20 @@ def main():
     blob = blob_c.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)    # Conv_Body output, channels-last
     feat = feat_c.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)    # Prd_RCNN2D output
 
-    def step():
-        return model(frames, blob, feat, rois, topk=100, prd_k=1)
+    state = dict(resident=False)
 
-    for _ in range(args.warmup):
+    def step():
+        # the inputs stay resident in the buffers the captured step graph reads (no per-step copy); with two
+        # graph instances in flight each has its own copy of the (identical) synthetic inputs
+        f, b, m_ = model.step_buffers() if state["resident"] else (frames, blob, feat)
+        return model(f, b, m_, rois, topk=100, prd_k=1)
+
+    for _ in range(max(args.warmup, args.pipeline)):
         outs = step()
-    # the inputs stay resident in the buffers the captured step graph reads (no per-step copy)
-    frames, blob, feat = model.step_buffers()
-    outs = step()
+    state["resident"] = True
+    for _ in range(args.pipeline):
+        outs = step()
+    model.sync_steps()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -122,6 +131,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         outs = step()
+    model.sync_steps()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

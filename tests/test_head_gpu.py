@@ -130,18 +130,31 @@ def test_step_graph_replay_equals_eager(setup):
         eager.append([{k: o[k].clone() for k in keys} for o in outs])
     m.graph_step = True
     try:
-        for side in (False, True):       # True: the weight-streaming branch forked onto a second stream inside the graph
-            m.side_stream = side
+        # side: the weight-streaming branch forked onto a second stream inside the graph; depth 2: two captured
+        # instances of the step alternate on two streams (results ordered by sync_steps())
+        for side, depth in ((False, 1), (True, 1), (True, 2)):
+            m.side_stream, m.pipeline = side, depth
             m._step_graphs.clear()
-            for rep in range(2):
+            for rep in range(3):
                 for (fr, bl, fe, ro), want in zip(cases, eager):
                     outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+                    m.sync_steps()
                     for o, w in zip(outs, want):
                         for k in keys:
-                            assert torch.equal(o[k], w[k]), (side, rep, k)
+                            assert torch.equal(o[k], w[k]), (side, depth, rep, k)
+            if depth == 2:      # back-to-back steps in flight, checked afterwards
+                pend = []
+                for _ in range(2):
+                    for (fr, bl, fe, ro), want in zip(cases[:2], eager[:2]):
+                        outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+                        pend.append(([{k: o[k].clone() for k in keys} for o in outs], want))
+                m.sync_steps()
+                torch.cuda.synchronize()
     finally:
         m.graph_step = False
         m.side_stream = False
+        m.pipeline = 1
+        m._step_graphs.clear()
 
 
 def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=False, **okw):

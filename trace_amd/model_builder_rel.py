@@ -164,6 +164,10 @@ class Generalized_RCNN(nn.Module):
         self._pk_epoch = 0
         self._side_streams = {}
         self.side_stream = False
+        # step graphs in flight: 2 = two captured instances of the step alternate on two streams, so the latency-bound
+        # head of step i overlaps the backbone of step i+1 (results of a step are ordered on the caller's stream by
+        # the next call or sync_steps()).  Measured on MI355X: no gain over depth 1 (2634 vs 2653 clips/s), so 1 is the default
+        self.pipeline = 1
         self.side_fork_stage = 1      # fork after layer2 (0-based residual stage index; -1 = after the stem)
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
@@ -347,7 +351,15 @@ class Generalized_RCNN(nn.Module):
         dev = all_frames.device
         key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch)
-        ent = self._step_graphs.get(key)
+        depth = max(1, int(self.pipeline))
+        ents = self._step_graphs.get(key)
+        if ents is None:
+            ents = self._step_graphs[key] = dict(inst=[None] * depth, calls=0)
+        if len(ents["inst"]) != depth:
+            raise RuntimeError("pipeline depth changed under captured step graphs: clear model._step_graphs first")
+        k = ents["calls"] % depth
+        ent = ents["inst"][k]
+        cur = torch.cuda.current_stream(dev)
         if ent is None:
             frames_s = all_frames.detach().clone(memory_format=torch.contiguous_format)
             blob_s, fmap_s = self._nhwc(blob_conv).clone(), self._nhwc(feat_map).clone()
@@ -358,21 +370,24 @@ class Generalized_RCNN(nn.Module):
             # step k still runs
             pinned = torch.zeros((2 * nb,), dtype=torch.uint8, pin_memory=True)
             counter = torch.zeros((2,), dtype=torch.int32, device=dev)   # [launch number, arrival count]
-            dv = prep["upl"].commit(dev, into=dv_buf[:max(prep["upl"].nbytes, 256)])
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):            # packs weights, sizes workspaces, warms the allocator
-                self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            dv = prep["upl"].views(dv_buf)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                ops.upload_slots(pinned, nb, counter, dv_buf, nb)
-                res = self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
+            torch.cuda.synchronize(dev)              # earlier instances may be running on their own streams
+            with ops.workspace_base(2 * k):          # concurrent instances keep their own split-K scratch
+                dv = prep["upl"].commit(dev, into=dv_buf[:max(prep["upl"].nbytes, 256)])
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):        # packs weights, sizes workspaces, warms the allocator
+                    self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
+                cur.wait_stream(side)
+                dv = prep["upl"].views(dv_buf)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ops.upload_slots(pinned, nb, counter, dv_buf, nb)
+                    res = self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
             ent = dict(graph=g, frames=frames_s, blob=blob_s, fmap=fmap_s, dv=dv_buf, res=res, pinned=pinned,
                        pinned_np=pinned.numpy(), counter=counter, slot_bytes=nb, seq=0, events=[None, None],
-                       nbytes=prep["upl"].nbytes)
-            self._step_graphs[key] = ent
+                       nbytes=prep["upl"].nbytes, stream=torch.cuda.Stream(device=dev) if depth > 1 else None,
+                       done=None, owner=ents)
+            ents["inst"][k] = ent
         if prep["upl"].nbytes != ent["nbytes"]:
             raise RuntimeError("upload layout changed under a captured step")
         slot = ent["seq"] & 1
@@ -380,26 +395,55 @@ class Generalized_RCNN(nn.Module):
         if ev is not None:
             ev.synchronize()                         # the replay that read this slot two steps ago has finished
         prep["upl"].fill(ent["pinned_np"][slot * ent["slot_bytes"]:(slot + 1) * ent["slot_bytes"]])
+        run = ent["stream"] if ent["stream"] is not None else cur
+        copied = False
+        if run is not cur and ent["done"] is not None:
+            cur.wait_event(ent["done"])              # input copies below must not overtake this instance's last replay
         if all_frames.data_ptr() != ent["frames"].data_ptr():
             ent["frames"].copy_(all_frames)
+            copied = True
         if blob_conv.data_ptr() != ent["blob"].data_ptr():
             ent["blob"].copy_(self._nhwc(blob_conv))
+            copied = True
         if feat_map.data_ptr() != ent["fmap"].data_ptr():
             ent["fmap"].copy_(self._nhwc(feat_map))
-        ent["graph"].replay()
-        ev = ent["events"][slot]
-        if ev is None:
-            ev = ent["events"][slot] = torch.cuda.Event()
-        ev.record()
+            copied = True
+        if run is not cur and copied:
+            run.wait_stream(cur)
+        with torch.cuda.stream(run):
+            ent["graph"].replay()
+            ev = ent["events"][slot]
+            if ev is None:
+                ev = ent["events"][slot] = torch.cuda.Event()
+            ev.record()
+        ent["done"] = ev
+        # pipeline depth > 1: the caller's stream is ordered behind the PREVIOUS step only, so this step overlaps
+        # the next one; its results are valid on the caller's stream after the next call or `sync_steps()`
+        prev = self._last_step_entry
+        if run is not cur and prev is not None and prev is not ent and prev["done"] is not None:
+            cur.wait_event(prev["done"])
         ent["seq"] += 1
+        ents["calls"] += 1
         self._last_step_entry = ent
         return ent["res"]
 
+    def sync_steps(self):
+        """Order the current stream behind every step still running on a pipeline stream (pipeline depth > 1)."""
+        for ents in self._step_graphs.values():
+            for ent in ents["inst"]:
+                if ent is not None and ent["done"] is not None and ent["stream"] is not None:
+                    torch.cuda.current_stream(ent["frames"].device).wait_event(ent["done"])
+
     def step_buffers(self):
-        """(clip, blob_conv, feat_map) input buffers of the most recently replayed step graph: a loader that
-        fills them in place (channels-last bf16 maps) saves the per-step copies."""
+        """(clip, blob_conv, feat_map) input buffers of the step-graph instance the NEXT call with the last step
+        signature will replay: a loader that fills them in place (channels-last bf16 maps) saves the per-step
+        copies.  With pipeline depth > 1 the instances alternate, so ask before every step."""
         e = self._last_step_entry
-        return e["frames"], e["blob"], e["fmap"]
+        ents = e["owner"]
+        nxt = ents["inst"][ents["calls"] % len(ents["inst"])]
+        if nxt is None:
+            nxt = e
+        return nxt["frames"], nxt["blob"], nxt["fmap"]
 
     @staticmethod
     def _nhwc(x):

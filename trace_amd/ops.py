@@ -48,10 +48,31 @@ class workspace_slot:
         return False
 
 
+_WS_BASE = 0
+
+
+class workspace_base:
+    """Launches made inside use scratch slots base + {0, 1}: step graphs that run concurrently on different
+    streams (model pipeline depth 2) must not share split-K scratch."""
+
+    def __init__(self, base):
+        self.base = base
+
+    def __enter__(self):
+        global _WS_BASE
+        self.prev, _WS_BASE = _WS_BASE, self.base
+        return self
+
+    def __exit__(self, *a):
+        global _WS_BASE
+        _WS_BASE = self.prev
+        return False
+
+
 def workspace(device):
     """Per-device (and per slot) split-K scratch handed to the igemm entry points (the library allocates
     nothing).  Calls that share a buffer must be ordered on one stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _WS_SLOT)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _WS_BASE + _WS_SLOT)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty((WORKSPACE_BYTES,), dtype=torch.uint8, device=torch.device("cuda", key[0]))
