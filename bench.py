@@ -146,6 +146,15 @@ def main():
             step()
         torch.cuda.synchronize()
         ops.IGEMM_TRACE = None
+        # what an (event, launch, event) bracket costs beyond the kernel itself: empty brackets on the same stream
+        empty = []
+        for _ in range(200):
+            s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record()
+            e0.record()
+            empty.append((s0, e0))
+        torch.cuda.synchronize()
+        event_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in empty]))
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -161,7 +170,7 @@ def main():
     value = world * B * args.steps / dt
     roof = None
     if trace:
-        ms = [t[0].elapsed_time(t[1]) for t in trace]
+        ms = [max(t[0].elapsed_time(t[1]) - event_overhead_ms, 1e-3) for t in trace]   # bracket overhead removed
         fl = [t[2] for t in trace]
         alg_bytes = sum(t[3] for t in trace) / len(trace)
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over
@@ -177,6 +186,7 @@ def main():
                     frac=achieved / MFMA_BF16_PEAK, traffic=traffic, traffic_unit="bytes per launch (PMC)",
                     algorithmic_bytes_per_launch=alg_bytes, kernel="trace::igemm*_bf16_kernel<*>",
                     launches_per_step=len(trace) // args.steps, avg_launch_us=avg_ms * 1e3,
+                    event_bracket_overhead_us=event_overhead_ms * 1e3,
                     gflop_per_step=sum(fl) / args.steps / 1e9)
     cpu = None
     if sd_cpu is not None:
