@@ -124,32 +124,40 @@ def test_step_graph_replay_equals_eager(setup):
     frames2, blob2, feat2, rois2 = make_inputs(2, 8, 6, 224, seed=12)
     cases = [(frames, blob, feat, rois), (frames2, blob2, feat2, rois2), (frames, blob, feat, [rois[0], rois[1][:4]])]
     keys = ("prd_scores", "det_labels", "msp_det_scores", "top_scores", "top_pair", "top_prd")
-    eager = []
-    for fr, bl, fe, ro in cases:
-        outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
-        eager.append([{k: o[k].clone() for k in keys} for o in outs])
-    m.graph_step = True
+
+    def run(case):
+        fr, bl, fe, ro = case
+        return m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+
     try:
-        # side: the weight-streaming branch forked onto a second stream inside the graph; depth 2: two captured
-        # instances of the step alternate on two streams (results ordered by sync_steps())
+        # side: part of the head forked onto a second stream (the pair pooling then runs as its own launch, so the
+        # eager reference is taken in the same mode); depth 2: two captured instances of the step alternate on two
+        # streams (results ordered by sync_steps())
         for side, depth in ((False, 1), (True, 1), (True, 2)):
-            m.side_stream, m.pipeline = side, depth
+            m.side_stream, m.pipeline, m.graph_step = side, depth, False
             m._step_graphs.clear()
+            eager = []
+            for case in cases:
+                outs = run(case)
+                torch.cuda.synchronize()
+                eager.append([{k: o[k].clone() for k in keys} for o in outs])
+            m.graph_step = True
             for rep in range(3):
-                for (fr, bl, fe, ro), want in zip(cases, eager):
-                    outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+                for case, want in zip(cases, eager):
+                    outs = run(case)
                     m.sync_steps()
                     for o, w in zip(outs, want):
                         for k in keys:
                             assert torch.equal(o[k], w[k]), (side, depth, rep, k)
-            if depth == 2:      # back-to-back steps in flight, checked afterwards
-                pend = []
-                for _ in range(2):
-                    for (fr, bl, fe, ro), want in zip(cases[:2], eager[:2]):
-                        outs = m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
-                        pend.append(([{k: o[k].clone() for k in keys} for o in outs], want))
+            if depth == 2:      # two steps in flight: the two instances hold the results of the last two calls
+                o_a = run(cases[0])
+                o_b = run(cases[1])
                 m.sync_steps()
                 torch.cuda.synchronize()
+                for outs, want in ((o_a, eager[0]), (o_b, eager[1])):
+                    for o, w in zip(outs, want):
+                        for k in keys:
+                            assert torch.equal(o[k], w[k]), ("in flight", k)
     finally:
         m.graph_step = False
         m.side_stream = False

@@ -161,6 +161,15 @@ def test_pair_infer_fused_vs_reference_order():
     err = float((got - ref).norm() / ref.norm())
     assert err < 2e-2, err
     assert float((got - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    # the two-launch form (pooling beside the backbone, combine after the tree-GRU): pooled maps pass through bf16
+    pooled = ops.pair_pool(vab.to(DEV), torch.from_numpy(rel).to(DEV), 1 / 16., 7)
+    sp2 = ops.pair_combine(pooled, (B, H, W), qk, torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV),
+                           torch.from_numpy(Y).int().to(DEV), bias.to(DEV), 1 / 16., 7)
+    got2 = sp2.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
+    assert float((got2 - ref).norm() / ref.norm()) < 2e-2
+    assert float((got2 - got).abs().max()) <= 2e-2 * float(ref.abs().max())
+    vp_got = pooled[:, :, :D].float().cpu().permute(0, 2, 1).reshape(P, D, 7, 7)
+    assert float((vp_got - vp).abs().max()) <= 1e-2 * float(vp.abs().max())
 
 
 @pytest.mark.parametrize("prd_k,topk", [(1, 100), (3, 100), (20, 50), (200, 7)])

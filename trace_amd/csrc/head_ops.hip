@@ -351,6 +351,155 @@ __global__ __launch_bounds__(256) void pair_infer_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The same computation as pair_infer_kernel in two launches, so that the heavy half leaves the critical
+// path: pair_pool_kernel (union-box pooling of [V | W_A V | W_B V]) needs only the 2-D feature map and the
+// pair boxes and runs beside the I3D backbone on the second stream; pair_combine_kernel (scores of the
+// scalar maps q.K, softmax over the cells, LeakyReLU(a_s VAp + a_o VBp + b) + Vp) is what remains after
+// the tree-GRU has produced the queries: a streaming pass over the pooled maps.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void pa_geometry(const float* r, int B, float scale, int PS, PGeom& g) {
+  g.batch = min(max((int)r[0], 0), B - 1);
+  g.start_w = r[1] * scale;
+  g.start_h = r[2] * scale;
+  const float end_w = r[3] * scale, end_h = r[4] * scale;
+  const float roi_w = fmaxf(end_w - g.start_w, 1.0f), roi_h = fmaxf(end_h - g.start_h, 1.0f);
+  g.bin_h = roi_h / (float)PS;
+  g.bin_w = roi_w / (float)PS;
+  g.grid_h = (int)ceilf(roi_h / (float)PS);
+  g.grid_w = (int)ceilf(roi_w / (float)PS);
+}
+
+__global__ __launch_bounds__(256) void pair_pool_kernel(const uint16_t* __restrict__ vab, int B, int H, int W, int D,
+                                                        const float* __restrict__ rel_rois, float scale, int PS,
+                                                        uint16_t* __restrict__ pooled) {
+  const int p = blockIdx.x;
+  const int cells = PS * PS;
+  const int lpb = D >> 3, bpr = 256 / lpb;
+  const int cg = threadIdx.x % lpb, slot = threadIdx.x / lpb;
+  PGeom g;
+  pa_geometry(rel_rois + (long long)p * 5, B, scale, PS, g);
+  const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
+  const uint16_t* img = vab + (long long)g.batch * H * W * (3 * D) + cg * 8;
+  for (int cell0 = 0; cell0 < cells; cell0 += bpr) {
+    const int cell = cell0 + slot;
+    if (cell >= cells) break;
+    const int ph = cell / PS, pw = cell - ph * PS;
+    float acc[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy)
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        PSample sm;
+        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint16_t* px = img + (long long)sm.pos[c] * (3 * D);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4*>(px + k * D);
+            const uint32_t* u = &v.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[k][2 * j] += sm.w[c] * __uint_as_float(u[j] << 16);
+              acc[k][2 * j + 1] += sm.w[c] * __uint_as_float(u[j] & 0xffff0000u);
+            }
+          }
+        }
+      }
+    uint16_t* o = pooled + ((long long)p * cells + cell) * (3 * D) + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint4 pk;
+      pk.x = pack_bf16x2(acc[k][0] * inv_count, acc[k][1] * inv_count);
+      pk.y = pack_bf16x2(acc[k][2] * inv_count, acc[k][3] * inv_count);
+      pk.z = pack_bf16x2(acc[k][4] * inv_count, acc[k][5] * inv_count);
+      pk.w = pack_bf16x2(acc[k][6] * inv_count, acc[k][7] * inv_count);
+      *reinterpret_cast<uint4*>(o + k * D) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pair_combine_kernel(
+    const uint16_t* __restrict__ pooled, int B, int H, int W, int D, const float* __restrict__ qk, int ld_qk,
+    const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
+    const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
+  __shared__ float sc_s[PA_MAX_CELLS], sc_o[PA_MAX_CELLS];
+  const int p = blockIdx.x;
+  const int cells = PS * PS;
+  const int lpb = D >> 3, bpr = 256 / lpb;
+  const int cg = threadIdx.x % lpb, slot = threadIdx.x / lpb;
+  PGeom g;
+  pa_geometry(rel_rois + (long long)p * 5, B, scale, PS, g);
+  const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
+  if (threadIdx.x < cells) {   // same summation order as pair_infer_kernel
+    const float* qs_row = qk + (long long)(2 * sbj[p]) * ld_qk + (long long)g.batch * H * W;
+    const float* qo_row = qk + (long long)(2 * obj[p] + 1) * ld_qk + (long long)g.batch * H * W;
+    const int cell = threadIdx.x;
+    const int ph = cell / PS, pw = cell - ph * PS;
+    float as = 0.f, ao = 0.f;
+    for (int iy = 0; iy < g.grid_h; ++iy)
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        PSample sm;
+        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          as += sm.w[c] * qs_row[sm.pos[c]];
+          ao += sm.w[c] * qo_row[sm.pos[c]];
+        }
+      }
+    sc_s[cell] = as * inv_count;
+    sc_o[cell] = ao * inv_count;
+  }
+  __syncthreads();
+  float ms = -__builtin_inff(), mo = -__builtin_inff();
+  for (int c = 0; c < cells; ++c) {
+    ms = fmaxf(ms, sc_s[c]);
+    mo = fmaxf(mo, sc_o[c]);
+  }
+  float ss = 0.f, so = 0.f;
+  for (int c = 0; c < cells; ++c) {
+    ss += expf(sc_s[c] - ms);
+    so += expf(sc_o[c] - mo);
+  }
+  const float is = 1.0f / ss, io = 1.0f / so;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = bias[cg * 8 + j];
+  for (int cell0 = 0; cell0 < cells; cell0 += bpr) {
+    const int cell = cell0 + slot;
+    if (cell >= cells) break;
+    const uint16_t* src = pooled + ((long long)p * cells + cell) * (3 * D) + cg * 8;
+    const uint4 v0 = *reinterpret_cast<const uint4*>(src);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(src + D);
+    const uint4 v2 = *reinterpret_cast<const uint4*>(src + 2 * D);
+    const uint32_t* u0 = &v0.x;
+    const uint32_t* u1 = &v1.x;
+    const uint32_t* u2 = &v2.x;
+    const float ws = expf(sc_s[cell] - ms) * is, wo = expf(sc_o[cell] - mo) * io;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float vl = __uint_as_float(u0[j] << 16), vh = __uint_as_float(u0[j] & 0xffff0000u);
+      const float al = __uint_as_float(u1[j] << 16), ah = __uint_as_float(u1[j] & 0xffff0000u);
+      const float bl = __uint_as_float(u2[j] << 16), bh = __uint_as_float(u2[j] & 0xffff0000u);
+      float t0 = ws * al + wo * bl + bv[2 * j], t1 = ws * ah + wo * bh + bv[2 * j + 1];
+      t0 = t0 > 0.f ? t0 : 0.1f * t0;
+      t1 = t1 > 0.f ? t1 : 0.1f * t1;
+      o[2 * j] = t0 + vl;
+      o[2 * j + 1] = t1 + vh;
+    }
+    uint4 pk;
+    pk.x = pack_bf16x2(o[0], o[1]);
+    pk.y = pack_bf16x2(o[2], o[3]);
+    pk.z = pack_bf16x2(o[4], o[5]);
+    pk.w = pack_bf16x2(o[6], o[7]);
+    *reinterpret_cast<uint4*>(sp + ((long long)p * cells + cell) * D + cg * 8) = pk;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Tree-GRU: one workgroup per (tree, feature group); levels are walked inside
 // the kernel (a tree is independent of every other tree), so the whole
 // bottom-up + top-down pass of all clips and groups is ONE launch.
@@ -870,6 +1019,34 @@ extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, 
   hipLaunchKernelGGL(pair_infer_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, qk, ld_qk, rel_rois,
                      sbj_inds, obj_inds, bias, spatial_scale, pooled, sp);
   return check_launch("pair_infer_fused");
+}
+
+extern "C" int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois, int P,
+                               float spatial_scale, int pooled, uint16_t* out, trace_stream_t stream) {
+  TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_pool: bad shape");
+  TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_pool: D=%d must be 64/128/256/512", D);
+  TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_pool: pooled=%d too large", pooled);
+  if (P == 0) return 0;
+  TRACE_REQUIRE(vab && rel_rois && out, "pair_pool: null pointer");
+  TRACE_REQUIRE((((uintptr_t)vab | (uintptr_t)out) & 15) == 0, "pair_pool: vab / out must be 16-byte aligned");
+  hipLaunchKernelGGL(pair_pool_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, rel_rois, spatial_scale,
+                     pooled, out);
+  return check_launch("pair_pool");
+}
+
+extern "C" int trace_pair_combine(const uint16_t* pooled_maps, int B, int H, int W, int D, const float* qk, int ld_qk,
+                                  const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
+                                  const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream) {
+  TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_combine: bad shape");
+  TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_combine: D=%d must be 64/128/256/512", D);
+  TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_combine: pooled=%d too large", pooled);
+  TRACE_REQUIRE(ld_qk >= B * H * W, "pair_combine: ld_qk=%d smaller than B*H*W", ld_qk);
+  if (P == 0) return 0;
+  TRACE_REQUIRE(pooled_maps && qk && rel_rois && sbj_inds && obj_inds && bias && sp, "pair_combine: null pointer");
+  TRACE_REQUIRE((((uintptr_t)pooled_maps | (uintptr_t)sp) & 15) == 0, "pair_combine: maps / sp must be 16-byte aligned");
+  hipLaunchKernelGGL(pair_combine_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, pooled_maps, B, H, W, D, qk, ld_qk,
+                     rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled, sp);
+  return check_launch("pair_combine");
 }
 
 extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,

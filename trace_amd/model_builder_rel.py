@@ -172,6 +172,8 @@ class Generalized_RCNN(nn.Module):
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
+        self.split_pair_pool = False     # with side_stream: pool on the second stream, combine after the tree-GRU
+                                         # (measured no faster than the fused launch: 2.869 vs 2.852 ms/step)
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -675,6 +677,10 @@ class Generalized_RCNN(nn.Module):
                     w_vab, b_vab, bias_ab = self._cached("vab", make_vab)
                     vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
                     vmap = None
+                    # with the second stream the union-box pooling (the heavy half of the pair kernel) runs here,
+                    # beside the backbone; what depends on the queries is a streaming pass after the tree-GRU
+                    pa["pooled_vab"] = (ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps)
+                                        if self.side_stream and self.split_pair_pool else None)
                 else:
                     vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
                 # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
@@ -767,7 +773,11 @@ class Generalized_RCNN(nn.Module):
             q_so = self._gemm(lo, "att_so", [self.spatio_atten_s[1], self.spatio_atten_o[1]])
             q_s, q_o = q_so[:, :low], q_so[:, low:]
             qk = ops.gemm_nt(q_so.view(2 * Ntot, low), kmap.view(-1, low), out_f32=True)   # (2*Ntot, B*h*w)
-            sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps)
+            if pa.get("pooled_vab") is not None:
+                sp = ops.pair_combine(pa["pooled_vab"], tuple(vab.shape[:3]), qk, union_d, dv[ix["X32"]], dv[ix["Y32"]],
+                                      bias_ab, cfg.REL_SPATIAL_SCALE, ps)
+            else:
+                sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps)
         else:
             q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
             q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)

@@ -518,6 +518,41 @@ def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, poole
     return sp
 
 
+def pair_pool(vab, rel_rois, spatial_scale, pooled=7):
+    """Union-box pooling of vab (B,H,W,3D) bf16 -> (P, pooled*pooled, 3D) bf16 (first half of `pair_infer`)."""
+    vab = _bf16(vab, "vab")
+    rel_rois = _f32(rel_rois)
+    B, H, W, D3 = vab.shape
+    P = rel_rois.shape[0]
+    out = torch.empty((P, pooled * pooled, D3), dtype=torch.bfloat16, device=vab.device)
+    with torch.cuda.device(vab.device):
+        L.check(L.lib().trace_pair_pool(L.ptr(vab), B, H, W, D3 // 3, L.ptr(rel_rois), P, float(spatial_scale), pooled,
+                                        L.ptr(out), L.stream()), "pair_pool")
+    return out
+
+
+def pair_combine(pooled_maps, map_shape, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7):
+    """Second half of `pair_infer`: pooled_maps (P, pooled*pooled, 3D) from `pair_pool`, map_shape = (B, H, W)."""
+    pooled_maps = _bf16(pooled_maps, "pooled_maps")
+    rel_rois, bias = _f32(rel_rois), _f32(bias)
+    L.require_gpu(sbj_inds, obj_inds, qk)
+    if qk.dtype != torch.float32 or qk.dim() != 2 or qk.stride(1) != 1:
+        raise RuntimeError("pair_combine: qk must be 2-D f32 with contiguous rows")
+    if sbj_inds.dtype != torch.int32 or obj_inds.dtype != torch.int32:
+        raise RuntimeError("pair_combine: indices must be int32")
+    B, H, W = map_shape
+    P, cells, D3 = pooled_maps.shape
+    D = D3 // 3
+    if qk.shape[1] < B * H * W or bias.numel() != D or cells != pooled * pooled or rel_rois.shape[0] != P:
+        raise RuntimeError("pair_combine: shape mismatch")
+    sp = torch.empty((P, cells, D), dtype=torch.bfloat16, device=pooled_maps.device)
+    with torch.cuda.device(pooled_maps.device):
+        L.check(L.lib().trace_pair_combine(L.ptr(pooled_maps), B, H, W, D, L.ptr(qk), qk.stride(0), L.ptr(rel_rois),
+                                           L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()), P, L.ptr(bias),
+                                           float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_combine")
+    return sp
+
+
 def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
     """x (n_nodes, n_groups*F) f32; forest = dict(tree_off, level_off, n_levels, parent, child_off,
     child_idx) of int32 device tensors; weights = list (per group) of dicts holding the 16 TRANSPOSED
