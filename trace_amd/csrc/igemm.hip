@@ -1361,6 +1361,9 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
   if (nst < 2) nst = 2;
   if (nst > 4) nst = 4;
   while (nst > 2 && nst * stage > 160 * 1024) --nst;  // 160 KiB of LDS per CU
+  // a K slice shorter than the ring touches only its first ks_per stages (the loops never issue past the slice):
+  // allocate just those, so that single-K-step layers (64 -> 256 1x1x1 at 200704 positions) get 4 workgroups per CU
+  const int lds_stages = (v3 && p.ks_per < nst) ? p.ks_per : nst;
   {
 #define TRACE_IGEMM2(D, S)                                                                               \
   do {                                                                                                   \
@@ -1380,7 +1383,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * stage));           \
       attr_done3 = true;                                                                                 \
     }                                                                                                    \
-    hipLaunchKernelGGL((igemm3_bf16_kernel<WM, WN, D, S>), grid, dim3(256), S * stage, s, p);           \
+    hipLaunchKernelGGL((igemm3_bf16_kernel<WM, WN, D, S>), grid, dim3(256), lds_stages * stage, s, p);  \
   } while (0)
     // v3 main loop (eligibility computed above): a K-step must not straddle a tap, taps must fit the 32-bit
     // validity mask, a halo pointer must stay inside the zero page while it walks a tap
