@@ -31,6 +31,13 @@ CASES = [
     (1, 128, 2, 14, 14, 128, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
     (1, 192, 3, 7, 7, 72, (3, 3, 3), (2, 1, 1), (1, 1, 1), (1, 1, 1)),   # odd sizes, K tail
     (3, 8, 2, 5, 5, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1)),       # tiny
+    # 1x3x3 stride-1 convs big enough for the shared-patch kernel (sconv9): 14-row / 8-row tiles, dilation 1 / 2,
+    # one / even / odd numbers of 64-channel chunks, ragged map edges and a ragged last cout tile
+    (2, 128, 4, 40, 40, 192, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (2, 192, 4, 30, 20, 320, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
+    (4, 256, 4, 14, 14, 256, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
+    (4, 64, 4, 14, 14, 248, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2)),
+    (2, 64, 8, 56, 56, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1)),
 ]
 
 

@@ -12,7 +12,7 @@ import json
 import sys
 
 
-FAMILY = ("igemm2_bf16_kernel", "igemm3_bf16_kernel", "tconv3_bf16_kernel", "stem16_bf16_kernel", "wsgemm_bf16_kernel")
+FAMILY = ("igemm2_bf16_kernel", "igemm3_bf16_kernel", "tconv3_bf16_kernel", "stem16_bf16_kernel", "wsgemm_bf16_kernel", "sconv9_bf16_kernel")
 
 
 def per_launch(path, counter):
@@ -26,7 +26,7 @@ def per_launch(path, counter):
 
 fetch_kib, n1 = per_launch(sys.argv[1], "FETCH_SIZE")
 write_kib, n2 = per_launch(sys.argv[2], "WRITE_SIZE")
-out = dict(kernel="trace::{igemm2,igemm3,tconv3,stem16}_bf16_kernel<*>", launches=[n1, n2], fetch_size_kib_per_launch=fetch_kib,
+out = dict(kernel="trace::{igemm2,igemm3,tconv3,sconv9,stem16}_bf16_kernel<*>", launches=[n1, n2], fetch_size_kib_per_launch=fetch_kib,
            write_size_kib_per_launch=write_kib, fetch_correction=2.0,
            traffic_bytes_per_launch=(2.0 * fetch_kib + write_kib) * 1024.0,
            source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-trace`")

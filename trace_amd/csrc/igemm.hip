@@ -24,6 +24,7 @@
 //   * the same kernel runs plain/batched GEMMs (1 tap, explicit row strides).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace trace {
 
@@ -1281,6 +1282,254 @@ static int launch_tconv3(IgemmParams& p, int N, hipStream_t s) {
   return check_launch("conv3d_tconv3");
 }
 
+// ---------------------------------------------------------------------------------------------
+// Spatial 1x3x3 conv (stride 1, pad = dilation 1 or 2; conv2 of every Bottleneck3d, lib/i3d/resnet3d.py:199-207,
+// 43 % of the backbone's MACs) with the input patch shared by the nine taps.  Through the generic loop every
+// tap is its own K-step and re-fetches the (shifted) activation tile from L2: 9 x (A + B) per 64 input channels,
+// and the layers are operand-delivery bound (L2 -> LDS), not MFMA bound.  Here a tile is TH = 2 WN output rows x
+// 16 output columns of ONE frame and 64 couts; per 64-channel chunk its halo patch ((TH + 2D) rows x (16 + 2D)
+// pixels, row pitch 24 pixels, one pixel = one 128-byte swizzled LDS row) is loaded ONCE and tap (dy, dx) of
+// fragment j (= output row j of the wave's half) is patch-row fragment (j + dy D) - so the WN + 2D row fragments of a
+// column dx are read ONCE (immediate offsets) and serve its three dy taps from registers - taken dx D pixels to the
+// right - one of three per-lane base registers (the pitch is a multiple of 8 pixels, so only dx changes the XOR
+// swizzle phase).  Per chunk: one patch load + nine 8 KB weight loads
+// (4-stage ring, three K-steps in flight).  The patch of chunk c+1 is fetched in slices of SL loads per lane behind
+// the weight loads of taps 0..5 of chunk c; the per-step wait is a counted vmcnt (see the main loop).
+// K order is (chunk, tap), not (tap, channel): same sum, different f32 rounding order than the generic loop.
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_PW = 24;                        // patch row pitch (pixels), % 8 == 0
+constexpr int SC_NA = 4;                         // weight ring depth
+template <int WN, int D, int KG>
+__global__ __launch_bounds__(256 * KG) void sconv9_bf16_kernel(const IgemmParams p) {
+  // KG = 2: eight waves; waves 4..7 repeat the 2 x 2 wave tile on the SECOND 32-wide half of every K-step (wave
+  // group g takes MFMA K block g) and the two partial tiles are added through LDS at the end.  Two waves per SIMD
+  // instead of one when the grid gives a CU a single workgroup: one wave's LDS reads hide behind the other's MFMAs.
+  constexpr int WM = 2;
+  constexpr int NWAVE = 4 * KG;
+  constexpr int NS2 = 2 / KG;                    // 32-wide K halves per wave and K-step
+  constexpr int TH = 2 * WN;                     // output rows per tile
+  constexpr int PR = TH + 2 * D;                 // patch rows
+  constexpr int GROUPS = PR * SC_PW / 8;         // 8-pixel groups = 1 KiB LDS-DMA wave instructions
+  constexpr int NI = (GROUPS + NWAVE - 1) / NWAVE;   // patch loads per lane per chunk
+  constexpr int SL = (NI + 5) / 6;               // loads per lane per slice (taps 0..5)
+  constexpr int AL = 8 / NWAVE;                  // weight loads per lane per K-step
+  constexpr int PATCH_BYTES = NWAVE * NI * 1024;
+  constexpr int A_BYTES = 64 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const asm_ = smem;                       // SC_NA weight stages
+  char* const bsm = smem + SC_NA * A_BYTES;      // 1 or 2 patch stages
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int H = p.Ho, W = p.Wo;
+  const int tiles_x = (W + 15) >> 4, tiles_y = (H + TH - 1) / TH;
+  const int tile_n = bid % p.tiles_n;            // cout tile fastest: neighbours share the patch in L2
+  int rest = bid / p.tiles_n;
+  const int tx = rest % tiles_x;
+  rest /= tiles_x;
+  const int ty = rest % tiles_y;
+  const int f = rest / tiles_y;                  // frame = n * To + t
+  const int cout0 = tile_n * 64;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int Cin = p.Crun;
+
+  const int kseg = (lane & 7) ^ (lane >> 3);
+  const char* ap[AL];      // weight rows: 1 KiB group wave + NWAVE i = couts 8 (wave + NWAVE i) .. + 8
+#pragma unroll
+  for (int i = 0; i < AL; ++i) {
+    const int row = min(cout0 + (wave + NWAVE * i) * 8 + (lane >> 3), p.Cout - 1);
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + kseg * 8);
+  }
+  const uint16_t* frame = p.in + (long long)(f / p.To) * p.in_n_stride + (long long)(f % p.To) * p.Hi * p.Wi * p.pix;
+  const char* bp[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int pixel = (wave + NWAVE * i) * 8 + (lane >> 3);
+    const int pr = pixel / SC_PW, pc = pixel - pr * SC_PW;
+    const int y = y0 - D + pr, x = x0 - D + pc;
+    const bool ok = pr < PR && pc < 16 + 2 * D && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+    bp[i] = ok ? reinterpret_cast<const char*>(frame + ((long long)y * W + x) * p.pix + kseg * 8) : zero;
+  }
+  const long long a_tap = 2LL * Cin, a_chunk = 2LL * BK - 16LL * Cin;   // byte steps: next tap / tap 0 of the next chunk
+  const int nchunks = Cin / BK;
+
+  // weights of K-step (chunk, pos): taps are visited column by column (pos = 3 dx + dy -> tap 3 dy + dx, so that the
+  // three dy taps of a column reuse the same patch-row fragments from registers): +3, +3, -5 taps, ..., then tap 0 of
+  // the next chunk
+  int a_pos_next = 0;      // pos of the next K-step to issue (uniform)
+  auto issue_a = [&](int stage) {
+    char* a = asm_ + stage * A_BYTES + wave * 1024;
+    const long long adv = a_pos_next == 8 ? a_chunk : (a_pos_next % 3 == 2 ? -5 * a_tap : 3 * a_tap);
+#pragma unroll
+    for (int i = 0; i < AL; ++i) {
+      glds16(ap[i], a + i * (NWAVE * 1024));
+      ap[i] += adv;
+    }
+    a_pos_next = a_pos_next == 8 ? 0 : a_pos_next + 1;
+  };
+  auto issue_patch = [&](int stage, int i) {     // load i of the lane: 8-pixel group wave + NWAVE i
+    glds16(bp[i], bsm + stage * PATCH_BYTES + (wave + NWAVE * i) * 1024);
+    bp[i] += 2 * BK;
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int aoffs[2][NS2], boffs[3][NS2];
+#pragma unroll
+  for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+    for (int h = 0; h < NS2; ++h) aoffs[odd][h] = lds_off(wm * (16 * WM) + perm_row(odd, fr), (kg * NS2 + h) * 4 + fq);
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int h = 0; h < NS2; ++h) {
+      const int px = fr + dx * D;
+      boffs[dx][h] = (wn * WN * SC_PW + px) * 128 + ((((kg * NS2 + h) * 4 + fq) ^ (px & 7)) << 4);
+    }
+
+  // prologue: the whole patch of chunk 0, then the weights of the first SC_NA - 1 K-steps (a chunk has 9 >= 3)
+#pragma unroll
+  for (int i = 0; i < NI; ++i) issue_patch(0, i);
+#pragma unroll
+  for (int k = 0; k < SC_NA - 1; ++k) issue_a(k);
+
+  // Loads retire in order, so "K-step v's weights have landed" = "at most the loads issued after them are still in
+  // flight".  Step u issues [weights of step u+3][patch slice of tap(u)]; the weights of step v were issued first
+  // in step v-3, hence the allowance slice(v-3) + AL + slice(v-2) + AL + slice(v-1).  Slices only exist on taps 0..5
+  // of a chunk that has a successor, so at tap 0 the allowance (2 AL) already implies the whole next patch has landed.
+  int astage = 0;          // ring stage of the current K-step (uniform)
+  for (int c = 0; c < nchunks; ++c) {
+    const bool steady = c + 1 < nchunks;          // a next chunk exists: its patch is fetched behind this chunk's weights
+    const int pst = c & 1;
+    const char* const bbase = bsm + pst * PATCH_BYTES;
+    bf16x8 brow[WN + 2 * D][NS2];   // patch-row fragments of the current column dx
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {   // tap = position in the visiting order (3 dx + dy)
+      const int dx = tap / 3, dy = tap % 3;
+      auto cnt = [&](int t) { return (t < 0 || t > 5) ? 0 : (NI - t * SL <= 0 ? 0 : (NI - t * SL < SL ? NI - t * SL : SL)); };
+      const int al_s = cnt(tap - 3) + cnt(tap - 2) + cnt(tap - 1) + 2 * AL;
+      const int al_l = (tap <= 7 ? AL : 0) + (tap <= 6 ? AL : 0);
+      switch (steady ? al_s : al_l) {     // two compile-time values after unrolling
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        case 11: wait_vmcnt<11>(); break;
+        case 12: wait_vmcnt<12>(); break;
+        case 13: wait_vmcnt<13>(); break;
+        default: wait_vmcnt<0>(); break;
+      }
+      __builtin_amdgcn_s_barrier();
+      if (tap + SC_NA - 1 <= 8 || steady) issue_a((astage + SC_NA - 1) & (SC_NA - 1));
+      if (steady) {
+#pragma unroll
+        for (int i = tap * SL; i < (tap + 1) * SL && i < NI && tap <= 5; ++i) issue_patch(pst ^ 1, i);
+      }
+      const char* a = asm_ + astage * A_BYTES;
+      if (dy == 0) {
+#pragma unroll
+        for (int h = 0; h < NS2; ++h)
+#pragma unroll
+          for (int r = 0; r < WN + 2 * D; ++r)
+            brow[r][h] = *reinterpret_cast<const bf16x8*>(bbase + boffs[dx][h] + r * (SC_PW * 128));
+      }
+#pragma unroll
+      for (int h = 0; h < NS2; ++h) {
+        bf16x8 af[WM];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + aoffs[i & 1][h]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], brow[j + dy * D][h], acc[i][j], 0, 0, 0);
+      }
+      astage = (astage + 1) & (SC_NA - 1);
+    }
+  }
+
+  if (KG == 2) {   // add the second K half's tile: [wave tile][register][lane] floats over the (now idle) operand stages
+    float* red = reinterpret_cast<float*>(smem) + w4 * (WM * WN * 4 * 64) + lane;
+    __syncthreads();
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((i * WN + j) * 4 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += red[((i * WN + j) * 4 + r) * 64];
+  }
+
+  int mrow[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int y = y0 + wn * WN + j, x = x0 + fr;
+    mrow[j] = (y < H && x < W) ? (f * H + y) * W + x : -1;
+  }
+  igemm_epilogue_rows<WM, WN>(p, acc, cout0, mrow, wm, fq, 0);
+}
+
+// TRACE_SCONV_KG=1|2 forces the wave-group count of sconv9 (A/B measurements); default: by workgroups per CU
+static const int g_sconv_kg = getenv("TRACE_SCONV_KG") ? atoi(getenv("TRACE_SCONV_KG")) : 0;
+
+template <int WN, int D, int KG>
+static int launch_sconv9_kg(IgemmParams& p, long long nwg, hipStream_t s) {
+  constexpr int NWAVE = 4 * KG;
+  constexpr int NI = ((2 * WN + 2 * D) * SC_PW / 8 + NWAVE - 1) / NWAVE;
+  constexpr int PATCH_BYTES = NWAVE * NI * 1024;
+  constexpr int LDS_MAX = 2 * PATCH_BYTES + SC_NA * 64 * 128;
+  static_assert(KG == 1 || PATCH_BYTES + SC_NA * 64 * 128 >= 4 * 2 * WN * 4 * 64 * 4, "reduction scratch must fit the operand stages");
+  p.tiles_n = ceil_div(p.Cout, 64);
+  p.ksplit = 1;
+  p.ks_per = 0;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv9_bf16_kernel<WN, D, KG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    attr_done = true;
+  }
+  const int lds = (p.Crun > BK ? 2 : 1) * PATCH_BYTES + SC_NA * 64 * 128;   // one 64-channel chunk: no second patch stage
+  hipLaunchKernelGGL((sconv9_bf16_kernel<WN, D, KG>), dim3((unsigned)nwg), dim3(256 * KG), lds, s, p);
+  return check_launch("conv3d_sconv9");
+}
+
+template <int WN, int D>
+static int launch_sconv9(IgemmParams& p, long long nwg, hipStream_t s) {
+  // one workgroup per CU (by grid size or by its LDS footprint): eight waves, else four
+  const int kg = g_sconv_kg ? g_sconv_kg : (nwg <= 320 || p.Crun > BK ? 2 : 1);
+  return kg == 2 ? launch_sconv9_kg<WN, D, 2>(p, nwg, s) : launch_sconv9_kg<WN, D, 1>(p, nwg, s);
+}
+
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
   int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256,
@@ -1293,6 +1542,8 @@ static thread_local IgemmTune g_tune = {0, 0, 0};
 static const bool g_force_v2 = getenv("TRACE_IGEMM_V2") != nullptr;
 // TRACE_NO_TCONV=1 sends temporal convs through the generic loop (A/B measurements)
 static const bool g_no_tconv = getenv("TRACE_NO_TCONV") != nullptr;
+// TRACE_NO_SCONV=1 sends 1x3x3 convs through the generic loop (A/B measurements)
+static const bool g_no_sconv = getenv("TRACE_NO_SCONV") != nullptr;
 
 template <int WM, int WN>
 static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int ksplit_req) {
@@ -1431,6 +1682,18 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
       case 4: return small ? launch_tconv3<2, 5>(p, N, s) : launch_tconv3<4, 5>(p, N, s);
       default: return small ? launch_tconv3<2, 6>(p, N, s) : launch_tconv3<4, 6>(p, N, s);
     }
+  }
+  // spatial 1x3x3 convs (stride 1, pad = dilation): the halo patch is shared by the nine taps (sconv9_bf16_kernel)
+  if (!tile && !g_force_v2 && !g_no_sconv && batch == 1 && !p.narrow && p.kt == 1 && p.kh == 3 && p.kw == 3 && p.st == 1 &&
+      p.sh == 1 && p.sw == 1 && p.pt == 0 && p.ph == p.dh && p.pw == p.dw && p.dh == p.dw && (p.dh == 1 || p.dh == 2) &&
+      p.Crun % BK == 0 && p.Crun <= 2048 && p.Ktot == 9 * p.Crun && p.Ho == p.Hi && p.Wo == p.Wi && p.To == p.Ti &&
+      p.M < 0x40000000 && p.M % (p.Ho * p.Wo) == 0) {
+    const long long F = p.M / (p.Ho * p.Wo);
+    const long long per_frame = (long long)ceil_div(p.Wo, 16) * ceil_div(p.Cout, 64);
+    const long long wg14 = F * ceil_div(p.Ho, 14) * per_frame, wg8 = F * ceil_div(p.Ho, 8) * per_frame;
+    // 14-row tiles (fewest weight re-reads) when they still give every CU a workgroup, else 8-row tiles
+    if (wg14 >= 200) return p.dh == 1 ? launch_sconv9<7, 1>(p, wg14, s) : launch_sconv9<7, 2>(p, wg14, s);
+    if (wg8 >= 128) return p.dh == 1 ? launch_sconv9<4, 1>(p, wg8, s) : launch_sconv9<4, 2>(p, wg8, s);
   }
   if (p.w_tiled) {   // pre-tiled weights: 128-cout tiles of the v3 loop only
     if (!p.dense || p.Cout % 128 != 0 || p.Ktot % BK != 0 || g_force_v2) {
