@@ -7,6 +7,7 @@
 // This file is compiled with -ffp-contract=off: the f32 NCHW forward reproduces
 // the CPU reference's rounding sequence bit for bit.
 #include "common.h"
+#include <stdlib.h>
 
 namespace trace {
 
@@ -371,6 +372,109 @@ __global__ __launch_bounds__(256) void roi_align_avg_nhwc_bf16_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Forward, channels-last bf16, 7x7 bins, SEPARABLE form.  The kernel above reads 4 corners per sample per bin
+// (49 x grid^2 x 4 sixteen-byte loads per lane and roi) and is L2-bandwidth bound: 514 MB of L2 reads for the
+// 38 MB the step's object rois need.  A bin is a Cartesian product of y samples and x samples and a sample is
+// dropped iff its y OR its x is out of range (ROIAlign_cuda.cu:22-31), so
+//   out[ph][pw] = sum_py sum_px  Wy[ph][py] Wx[pw][px] map[py][px]
+// with Wy / Wx the per-axis sums of the 1-D interpolation weights (/ grid).  One wave owns 128 channels of one
+// roi (2 per lane, 49 x 2 accumulators): every map pixel of the roi's box is read ONCE, folded into the 7 column
+// bins of its row (Wx from LDS, broadcast reads), and a finished row is folded into the row bins with non-zero
+// Wy.  (box_h x box_w) loads instead of 196 x grid^2; f32 accumulation in a different order than the kernel
+// above (feature-path tolerance; the bit-exact contract is the f32 NCHW kernel's).
+// ---------------------------------------------------------------------------
+constexpr int RS_MAX_DIM = 64;   // map height / width limit of the separable forward kernel
+__global__ __launch_bounds__(64) void roi_align_fwd_sep7_nhwc_bf16_kernel(
+    const uint16_t* __restrict__ in, int B, int H, int W, int C, const float* __restrict__ rois,
+    float scale, int sr, uint16_t* __restrict__ out) {
+  constexpr int P = 7;
+  __shared__ __attribute__((aligned(16))) float wyT[RS_MAX_DIM][8];   // [pixel row][bin], bin 7 = padding
+  __shared__ __attribute__((aligned(16))) float wxT[RS_MAX_DIM + 16][8];   // 16 zero rows behind the map's last column
+  __shared__ int box[4];
+  const int n = blockIdx.y;
+  const int c0 = blockIdx.x * 128 + threadIdx.x * 2;
+  for (int e = threadIdx.x; e < 16 * 8; e += 64) wxT[W + (e >> 3)][e & 7] = 0.f;
+  RoiGeom g = roi_geom(rois + (long long)n * 5, scale, P, P, sr, B);
+  const uint16_t* img = in + (long long)g.batch * H * W * C + c0;
+  for (int e = threadIdx.x; e < (H + W) * 8; e += 64) {
+    const int q = e >> 3, b = e & 7;
+    const bool is_y = q < H;
+    const int pix = is_y ? q : q - H;
+    const int grid = is_y ? g.grid_h : g.grid_w, dim = is_y ? H : W;
+    const float start = is_y ? g.start_h : g.start_w, bsz = is_y ? g.bin_h : g.bin_w;
+    float acc = 0.f;
+    if (b < P) {
+      for (int i = 0; i < grid; ++i) {
+        const Lin1 l = lin_setup(sample_coord(start, b, bsz, i, grid), dim);
+        if (!l.valid) continue;
+        if (l.lo == pix) acc += l.wl;
+        if (l.hi == pix) acc += l.wh;
+      }
+      acc /= (float)grid;
+    }
+    (is_y ? wyT : wxT)[pix][b] = acc;
+  }
+  if (threadIdx.x < 4) {
+    // pixel range touched by the first / last sample of each axis (samples are monotonic)
+    const bool is_y = threadIdx.x < 2;
+    const int grid = is_y ? g.grid_h : g.grid_w, dim = is_y ? H : W;
+    const float start = is_y ? g.start_h : g.start_w, bsz = is_y ? g.bin_h : g.bin_w;
+    const bool first = (threadIdx.x & 1) == 0;
+    const Lin1 l = lin_setup(first ? sample_coord(start, 0, bsz, 0, grid) : sample_coord(start, P - 1, bsz, grid - 1, grid), dim);
+    box[threadIdx.x] = first ? l.lo : l.hi;
+  }
+  __syncthreads();
+  const int y0 = box[0], y1 = box[1], x0 = box[2], x1 = box[3];
+  float acc[P][P][2];
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = 0; b < P; ++b) acc[a][b][0] = acc[a][b][1] = 0.f;
+  for (int py = y0; py <= y1; ++py) {
+    const uint16_t* rowp = img + (long long)py * W * C;
+    float row[P][2];
+#pragma unroll
+    for (int b = 0; b < P; ++b) row[b][0] = row[b][1] = 0.f;
+    for (int xb = x0; xb <= x1; xb += 4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)   // no branch inside a group of 4, so its loads go out back to back; columns past the
+        v[k] = *reinterpret_cast<const uint32_t*>(rowp + (long long)min(xb + k, W - 1) * C);   // map re-read its last one, Wx = 0
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 wa = *reinterpret_cast<const float4*>(&wxT[xb + k][0]);
+        const float4 wb = *reinterpret_cast<const float4*>(&wxT[xb + k][4]);
+        const float w[P] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z};
+        const float f0 = __uint_as_float(v[k] << 16), f1 = __uint_as_float(v[k] & 0xffff0000u);
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+          row[b][0] += w[b] * f0;
+          row[b][1] += w[b] * f1;
+        }
+      }
+    }
+    const float4 ya = *reinterpret_cast<const float4*>(&wyT[py][0]);
+    const float4 yb = *reinterpret_cast<const float4*>(&wyT[py][4]);
+    const float wy[P] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z};
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+      if (wy[a] == 0.f) continue;   // uniform: a map row feeds the one or two row bins around it
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        acc[a][b][0] += wy[a] * row[b][0];
+        acc[a][b][1] += wy[a] * row[b][1];
+      }
+    }
+  }
+  uint16_t* dst = out + (long long)n * P * P * C + c0;
+#pragma unroll
+  for (int a = 0; a < P; ++a)
+#pragma unroll
+    for (int b = 0; b < P; ++b)
+      *reinterpret_cast<uint32_t*>(dst + (long long)(a * P + b) * C) = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
+}
+
 static int grid_for(long long n) {
   long long b = (n + 255) / 256;
   if (b > 256LL * 32) b = 256LL * 32;
@@ -459,6 +563,14 @@ extern "C" int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H
   if (K == 0 || C == 0) return 0;
   TRACE_REQUIRE(K <= 65535, "roi_align_fwd_nhwc: K=%d exceeds 65535 rois per call", K);
   TRACE_REQUIRE(input && rois && out, "roi_align_fwd_nhwc: null pointer");
+  static const bool no_sep = getenv("TRACE_ROI_NO_SEP") != nullptr;   // A/B measurements
+  // measured (160 rois x 2048 ch on 14x14 maps): sampling_ratio 2: 37.4 -> 26.6 us; adaptive grids (mostly 1x1 samples per bin
+  // at this map size) are cheaper per bin than per pixel (19.3 vs 23.5 us) and stay on the per-bin kernel
+  if (!no_sep && sampling_ratio >= 2 && pooled_h == 7 && pooled_w == 7 && H <= RS_MAX_DIM && W <= RS_MAX_DIM && C % 128 == 0) {
+    hipLaunchKernelGGL(roi_align_fwd_sep7_nhwc_bf16_kernel, dim3(C / 128, K), dim3(64), 0, (hipStream_t)stream,
+                       input, B, H, W, C, rois, spatial_scale, sampling_ratio, out);
+    return check_launch("roi_align_fwd_sep7_nhwc_bf16");
+  }
   int threads = C / 8 >= 256 ? 256 : ((C / 8 + 63) / 64) * 64;
   hipLaunchKernelGGL(roi_align_fwd_nhwc_bf16_kernel, dim3(pooled_h * pooled_w, K), dim3(threads), 0,
                      (hipStream_t)stream, input, B, H, W, C, rois, spatial_scale, pooled_h, pooled_w,
