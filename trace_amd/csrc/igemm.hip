@@ -1723,7 +1723,15 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     else if (p.ws && batch == 1 && p.M <= 192 && ksteps >= 1024)                  // weight streaming + split-K:
       tile = p.M <= 64 ? 3 : (p.M <= 128 ? 4 : 8);                                //   all positions in one tile
     else if (p.ws && batch == 1 && ksteps >= 128 && blocks(128, 128) <= 128) tile = 4;   // deep K: big tiles + split-K
-    else if (blocks(128, 128) >= 384) tile = 4;
+    else if (blocks(128, 128) >= 384) {
+      // whole rounds of workgroups matter for mid-sized grids: 128x128 tiles (64 KB, 2 per CU = 512 slots) against
+      // 128c x 64p (48 KB, 3 per CU = 768 slots), cost = rounds x operand bytes per K-step.  Cold sweep
+      // (scratch/sweep_dense.py): 6272 x 1536 x 1024 (588 tiles = 2 rounds of 512) 34.5 -> 29.9 us with the smaller
+      // tile; every other backbone shape keeps 128x128 under the same rule
+      tile = 4;
+      const long long b4 = blocks(128, 128), b3 = blocks(128, 64);
+      if (ksteps >= 8 && b4 <= 1536 && ((b3 + 767) / 768) * 192 < ((b4 + 511) / 512) * 256) tile = 3;
+    }
     else if (blocks(128, 64) >= 384) tile = 3;
     else tile = 1;                                                                // 64 x 64: small problems
   }
