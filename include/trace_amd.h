@@ -312,9 +312,14 @@ int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* vmap,
  *   object i against every position of every clip, row 2i+1 = q_o;  bias (D) f32 = b_A + b_B;
  *   sp (P, PH*PW, D) bf16 = LeakyReLU(a_s VAp + a_o VBp + bias) + Vp, a = softmax over the cells.
  * s_map / o_map / v_map are never written and the (P*PH*PW) x 2D x D GEMM of the reference's two convs is gone. */
+/* partner (P) int32 or NULL: partner[p] = index of the pair with subject and object swapped, -1 if it is not in the
+ * list.  rois_union (boxes_rel.py:100-106) is symmetric, so both pairs pool the same cells: the pair with the lower
+ * index pools once and writes both rows of sp.  The caller guarantees rel_rois[partner[p]] == rel_rois[p] and
+ * partner[partner[p]] == p.  Results are identical with and without it. */
 int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, const float* qk, int ld_qk,
-                           const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
-                           const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream);
+                           const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds,
+                           const int32_t* partner, int P, const float* bias, float spatial_scale, int pooled,
+                           uint16_t* sp, trace_stream_t stream);
 
 /* trace_pair_infer_fused as two launches (same references): trace_pair_pool writes the union-box pooling of
  * vab, out (P, PH*PW, 3D) bf16 = [Vp | (W_A V)p | (W_B V)p] - it needs only the 2-D map and the pair boxes, so a

@@ -161,6 +161,14 @@ def test_pair_infer_fused_vs_reference_order():
     err = float((got - ref).norm() / ref.norm())
     assert err < 2e-2, err
     assert float((got - ref).abs().max()) <= 3e-2 * float(ref.abs().max())
+    # swapped pairs share their union box: pooled once for both, bit-identical rows
+    from trace_amd.model_builder_rel import swapped_pair_index
+    part = swapped_pair_index(X, Y)
+    assert (part >= 0).sum() >= 2
+    sp_sh = ops.pair_infer(vab.to(DEV), qk, torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV),
+                           torch.from_numpy(Y).int().to(DEV), bias.to(DEV), 1 / 16., 7,
+                           partner=torch.from_numpy(part).to(DEV))
+    assert torch.equal(sp_sh, sp)
     # the two-launch form (pooling beside the backbone, combine after the tree-GRU): pooled maps pass through bf16
     pooled = ops.pair_pool(vab.to(DEV), torch.from_numpy(rel).to(DEV), 1 / 16., 7)
     sp2 = ops.pair_combine(pooled, (B, H, W), qk, torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV),

@@ -61,3 +61,26 @@ def test_batched_host_prep_is_byte_identical_to_per_clip(B, n, monkeypatch):
         assert a[k] == b[k], k
     for pa, pb in zip(a["pairs"], b["pairs"]):
         assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1])
+
+
+def test_swapped_pair_index():
+    """partner[p] is the pair with subject and object swapped; -1 where the list does not hold it."""
+    from trace_amd.model_builder_rel import swapped_pair_index
+    n = 6
+    s = np.repeat(np.arange(n), n - 1)
+    o = np.tile(np.arange(n - 1), n)
+    o = o + (o >= s)
+    part = swapped_pair_index(s, o)
+    assert np.array_equal(s[part], o) and np.array_equal(o[part], s) and np.array_equal(part[part], np.arange(len(s)))
+    # person-only subjects (Action Genome): objects never appear as subjects -> only person-person pairs match
+    keep = s < 2
+    part = swapped_pair_index(s[keep], o[keep])
+    ss, oo = s[keep], o[keep]
+    for p_, q_ in enumerate(part):
+        if oo[p_] < 2:
+            assert ss[q_] == oo[p_] and oo[q_] == ss[p_]
+        else:
+            assert q_ == -1
+    assert swapped_pair_index([0], [0]).tolist() == [-1]
+    assert swapped_pair_index([], []).shape == (0,)
+    assert swapped_pair_index([0, 0, 1, 1], [1, 1, 0, 0]).tolist() == [2, -1, 0, -1]

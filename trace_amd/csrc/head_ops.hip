@@ -240,10 +240,17 @@ __device__ __forceinline__ bool pa_sample(const PGeom& g, int PS, int H, int W, 
 __global__ __launch_bounds__(256) void pair_infer_kernel(
     const uint16_t* __restrict__ vab, int B, int H, int W, int D, const float* __restrict__ qk, int ld_qk,
     const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
-    const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
-  __shared__ float sc_s[PA_MAX_CELLS], sc_o[PA_MAX_CELLS];
+    const int32_t* __restrict__ partner, const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
+  // partner[p] = the pair with subject and object swapped (-1: none).  Both have the same union box, hence the same
+  // pooled [V | W_A V | W_B V] cells - 95 % of this kernel's work: the workgroup of the lower index pools once and
+  // writes both pairs (each with its own softmax weights), the other one exits.
+  __shared__ float sc_s[2][PA_MAX_CELLS], sc_o[2][PA_MAX_CELLS];
   const int p = blockIdx.x;
   const int cells = PS * PS;
+  const bool share = partner != nullptr && cells <= 64;
+  const int q = share ? partner[p] : -1;
+  if (q >= 0 && q < p) return;
+  const int npair = q > p ? 2 : 1;
   const int lpb = D >> 3;
   const int bpr = 256 / lpb;
   const int cg = threadIdx.x % lpb;
@@ -264,38 +271,49 @@ __global__ __launch_bounds__(256) void pair_infer_kernel(
   }
   const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
 
-  // phase 1: pooled scores of the two scalar maps, one thread per cell (fixed summation order)
-  if (threadIdx.x < cells) {
-    const float* qs_row = qk + (long long)(2 * sbj[p]) * ld_qk + (long long)g.batch * H * W;
-    const float* qo_row = qk + (long long)(2 * obj[p] + 1) * ld_qk + (long long)g.batch * H * W;
-    const int cell = threadIdx.x;
-    const int ph = cell / PS, pw = cell - ph * PS;
-    float as = 0.f, ao = 0.f;
-    for (int iy = 0; iy < g.grid_h; ++iy)
-      for (int ix = 0; ix < g.grid_w; ++ix) {
-        PSample sm;
-        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+  // phase 1: pooled scores of the two scalar maps, one thread per cell (fixed summation order); wave 1 takes the
+  // swapped pair
+  {
+    const int which = threadIdx.x >> 6, cell = threadIdx.x & 63;
+    if (which < npair && cell < cells) {
+      const int pp = which ? q : p;
+      const float* qs_row = qk + (long long)(2 * sbj[pp]) * ld_qk + (long long)g.batch * H * W;
+      const float* qo_row = qk + (long long)(2 * obj[pp] + 1) * ld_qk + (long long)g.batch * H * W;
+      const int ph = cell / PS, pw = cell - ph * PS;
+      float as = 0.f, ao = 0.f;
+      for (int iy = 0; iy < g.grid_h; ++iy)
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          PSample sm;
+          if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          as += sm.w[c] * qs_row[sm.pos[c]];
-          ao += sm.w[c] * qo_row[sm.pos[c]];
+          for (int c = 0; c < 4; ++c) {
+            as += sm.w[c] * qs_row[sm.pos[c]];
+            ao += sm.w[c] * qo_row[sm.pos[c]];
+          }
         }
-      }
-    sc_s[cell] = as * inv_count;
-    sc_o[cell] = ao * inv_count;
+      sc_s[which][cell] = as * inv_count;
+      sc_o[which][cell] = ao * inv_count;
+    }
   }
   __syncthreads();
-  float ms = -__builtin_inff(), mo = -__builtin_inff();
-  for (int c = 0; c < cells; ++c) {
-    ms = fmaxf(ms, sc_s[c]);
-    mo = fmaxf(mo, sc_o[c]);
+  float ms[2], mo[2], is[2], io[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    ms[k] = mo[k] = -__builtin_inff();
+    is[k] = io[k] = 0.f;
+    if (k >= npair) continue;
+    for (int c = 0; c < cells; ++c) {
+      ms[k] = fmaxf(ms[k], sc_s[k][c]);
+      mo[k] = fmaxf(mo[k], sc_o[k][c]);
+    }
+    float ss = 0.f, so = 0.f;
+    for (int c = 0; c < cells; ++c) {
+      ss += expf(sc_s[k][c] - ms[k]);
+      so += expf(sc_o[k][c] - mo[k]);
+    }
+    is[k] = 1.0f / ss;
+    io[k] = 1.0f / so;
   }
-  float ss = 0.f, so = 0.f;
-  for (int c = 0; c < cells; ++c) {
-    ss += expf(sc_s[c] - ms);
-    so += expf(sc_o[c] - mo);
-  }
-  const float is = 1.0f / ss, io = 1.0f / so;
 
   // phase 2: pool [V | W_A V | W_B V] and combine
   const uint16_t* img = vab + (long long)g.batch * H * W * (3 * D) + cg * 8;
@@ -333,20 +351,24 @@ __global__ __launch_bounds__(256) void pair_infer_kernel(
           }
         }
       }
-    const float ws = expf(sc_s[cell] - ms) * is * inv_count, wo = expf(sc_o[cell] - mo) * io * inv_count;
-    float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float t = ws * aa[j] + wo * ba[j] + bv[j];       // A(s_map) + B(o_map)  (:1039)
-      t = t > 0.f ? t : 0.1f * t;                      // LeakyReLU(0.1)
-      o[j] = t + va[j] * inv_count;                    // + V  (:1040)
+    for (int k = 0; k < 2; ++k) {
+      if (k >= npair) break;
+      const float ws = expf(sc_s[k][cell] - ms[k]) * is[k] * inv_count, wo = expf(sc_o[k][cell] - mo[k]) * io[k] * inv_count;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = ws * aa[j] + wo * ba[j] + bv[j];       // A(s_map) + B(o_map)  (:1039)
+        t = t > 0.f ? t : 0.1f * t;                      // LeakyReLU(0.1)
+        o[j] = t + va[j] * inv_count;                    // + V  (:1040)
+      }
+      uint4 pk;
+      pk.x = pack_bf16x2(o[0], o[1]);
+      pk.y = pack_bf16x2(o[2], o[3]);
+      pk.z = pack_bf16x2(o[4], o[5]);
+      pk.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(sp + ((long long)(k ? q : p) * cells + cell) * D + cg * 8) = pk;
     }
-    uint4 pk;
-    pk.x = pack_bf16x2(o[0], o[1]);
-    pk.y = pack_bf16x2(o[2], o[3]);
-    pk.z = pack_bf16x2(o[4], o[5]);
-    pk.w = pack_bf16x2(o[6], o[7]);
-    *reinterpret_cast<uint4*>(sp + ((long long)p * cells + cell) * D + cg * 8) = pk;
   }
 }
 
@@ -1006,9 +1028,9 @@ extern "C" int trace_pair_attention_fused(const uint16_t* kmap, const uint16_t* 
 }
 
 extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, const float* qk, int ld_qk,
-                                      const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
-                                      const float* bias, float spatial_scale, int pooled, uint16_t* sp,
-                                      trace_stream_t stream) {
+                                      const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds,
+                                      const int32_t* partner, int P, const float* bias, float spatial_scale, int pooled,
+                                      uint16_t* sp, trace_stream_t stream) {
   TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_infer: bad shape");
   TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_infer: D=%d must be 64/128/256/512", D);
   TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_infer: pooled=%d too large", pooled);
@@ -1017,7 +1039,7 @@ extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, 
   TRACE_REQUIRE(vab && qk && rel_rois && sbj_inds && obj_inds && bias && sp, "pair_infer: null pointer");
   TRACE_REQUIRE((((uintptr_t)vab | (uintptr_t)sp) & 15) == 0, "pair_infer: vab / sp must be 16-byte aligned");
   hipLaunchKernelGGL(pair_infer_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, qk, ld_qk, rel_rois,
-                     sbj_inds, obj_inds, bias, spatial_scale, pooled, sp);
+                     sbj_inds, obj_inds, partner, bias, spatial_scale, pooled, sp);
   return check_launch("pair_infer_fused");
 }
 

@@ -53,6 +53,29 @@ def _bf(x):
     return x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16)
 
 
+def swapped_pair_index(X, Y):
+    """partner[p] = q with (X[q], Y[q]) == (Y[p], X[p]), -1 when the swapped pair is not in the list (person-only
+    subjects, overlap filter) or is p itself.  rois_union (boxes_rel.py:100-106) is symmetric, so p and q pool the same
+    union box: `ops.pair_infer` pools it once for both."""
+    X = np.asarray(X, np.int64)
+    Y = np.asarray(Y, np.int64)
+    if X.size == 0:
+        return np.zeros(0, np.int32)
+    base = int(max(X.max(), Y.max())) + 1
+    key = X * base + Y
+    order = np.argsort(key, kind="stable")
+    skey = key[order]
+    want = Y * base + X
+    pos = np.minimum(np.searchsorted(skey, want), len(skey) - 1)
+    q = order[pos]
+    ok = (skey[pos] == want) & (q != np.arange(len(X)))
+    part = np.where(ok, q, -1)
+    # keep only mutual, unique matches (duplicate pairs in a list would break the one-writer rule)
+    safe = part >= 0
+    safe[safe] = part[part[safe]] == np.nonzero(safe)[0]
+    return np.where(safe, part, -1).astype(np.int32)
+
+
 class _Upload:
     """All per-step host arrays (roi lists, forest CSR arrays, pair indices) travel in ONE pinned
     staging buffer and one stream-ordered copy: the reference uploads each list with a blocking
@@ -172,6 +195,7 @@ class Generalized_RCNN(nn.Module):
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
+        self.share_swapped_pairs = True  # (s,o) and (o,s) have one union box: pooled once for both
         self.split_pair_pool = False     # with side_stream: pool on the second stream, combine after the tree-GRU
                                          # (measured no faster than the fused launch: 2.869 vs 2.852 ms/step)
 
@@ -520,6 +544,8 @@ class Generalized_RCNN(nn.Module):
                   LCA=upl.add(np.concatenate([p[2] + moff[b] for b, p in enumerate(pairs)]).astype(np.int64)),
                   X32=upl.add(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]).astype(np.int32)),
                   Y32=upl.add(np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]).astype(np.int32)),
+                  PART32=upl.add(swapped_pair_index(np.concatenate([p[0] + off[b] for b, p in enumerate(pairs)]),
+                                                    np.concatenate([p[1] + off[b] for b, p in enumerate(pairs)]))),
                   union=upl.add(np.concatenate([p[3] for p in pairs], 0)),
                   t_obj=upl.add(np.concatenate(t_obj, 0)), t_reg=upl.add(np.concatenate(t_reg, 0)),
                   reg=upl.add(np.concatenate(reg_rois, 0)),
@@ -589,6 +615,7 @@ class Generalized_RCNN(nn.Module):
                   X=upl.add(X.astype(np.int64)), Y=upl.add(Y.astype(np.int64)),
                   LCA=upl.add((lca + moff[:B, None]).reshape(-1).astype(np.int64)),
                   X32=upl.add(X.astype(np.int32)), Y32=upl.add(Y.astype(np.int32)),
+                  PART32=upl.add(swapped_pair_index(X, Y)),
                   union=upl.add(union.reshape(-1, 5)), t_obj=upl.add(t_obj), t_reg=upl.add(t_reg),
                   reg=upl.add(reg.reshape(-1, 5)),
                   pclip=upl.add(np.repeat(np.arange(B), P).astype(np.int64)), poff=upl.add(poff))
@@ -777,7 +804,8 @@ class Generalized_RCNN(nn.Module):
                 sp = ops.pair_combine(pa["pooled_vab"], tuple(vab.shape[:3]), qk, union_d, dv[ix["X32"]], dv[ix["Y32"]],
                                       bias_ab, cfg.REL_SPATIAL_SCALE, ps)
             else:
-                sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps)
+                sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps,
+                                    partner=dv[ix["PART32"]] if self.share_swapped_pairs else None)
         else:
             q_s = self._gemm(lo, "att_s", [self.spatio_atten_s[1]], out_f32=True)
             q_o = self._gemm(lo, "att_o", [self.spatio_atten_o[1]], out_f32=True)

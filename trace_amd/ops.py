@@ -494,10 +494,12 @@ def pair_attention(kmap, vmap, rel_rois, sbj_inds, obj_inds, q_s, q_o, spatial_s
     return s_map, o_map, v, so
 
 
-def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7):
+def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7, partner=None):
     """vab (B,H,W,3D) bf16 = [V | W_A V | W_B V]; qk (2*n_obj, >= B*H*W) f32 (row 2i = q_s of object i, 2i+1 = q_o);
     bias (D) f32 = b_A + b_B.  Returns sp (P, pooled*pooled, D) bf16 = LeakyReLU(A(s_map) + B(o_map)) + V
-    (model_builder_rel.py:1039-1040) without forming s_map / o_map."""
+    (model_builder_rel.py:1039-1040) without forming s_map / o_map.  partner (P) int32, optional: index of the pair
+    with subject and object swapped (-1: none; see `swapped_pair_index`): the two share one union box, so it is
+    pooled once for both."""
     vab = _bf16(vab, "vab")
     rel_rois, bias = _f32(rel_rois), _f32(bias)
     L.require_gpu(sbj_inds, obj_inds, qk)
@@ -512,8 +514,13 @@ def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, poole
         raise RuntimeError("pair_infer: qk / bias shape mismatch")
     sp = torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=vab.device)
     with torch.cuda.device(vab.device):
+        if partner is not None:
+            L.require_gpu(partner)
+            if partner.dtype != torch.int32 or partner.numel() != P or not partner.is_contiguous():
+                raise RuntimeError("pair_infer: partner must be a contiguous int32 tensor with one entry per pair")
         L.check(L.lib().trace_pair_infer_fused(L.ptr(vab), B, H, W, D, L.ptr(qk), qk.stride(0), L.ptr(rel_rois),
-                                               L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()), P, L.ptr(bias),
+                                               L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()),
+                                               None if partner is None else L.ptr(partner), P, L.ptr(bias),
                                                float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_infer")
     return sp
 
