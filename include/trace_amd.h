@@ -325,11 +325,13 @@ int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, cons
  * vab, out (P, PH*PW, 3D) bf16 = [Vp | (W_A V)p | (W_B V)p] - it needs only the 2-D map and the pair boxes, so a
  * caller can run it beside the I3D backbone; trace_pair_combine does what depends on the queries: pooled scores of
  * the scalar maps qk, softmax over the cells, sp = LeakyReLU(a_s VAp + a_o VBp + bias) + Vp. */
-int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois, int P,
-                    float spatial_scale, int pooled, uint16_t* out, trace_stream_t stream);
+/* partner (or NULL) as in trace_pair_infer_fused: only the lower index of a swapped pair is pooled (row p of
+ * `out`; the other row stays unwritten) and trace_pair_combine reads that row for both. */
+int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois, const int32_t* partner,
+                    int P, float spatial_scale, int pooled, uint16_t* out, trace_stream_t stream);
 int trace_pair_combine(const uint16_t* pooled_maps, int B, int H, int W, int D, const float* qk, int ld_qk,
-                       const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
-                       const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream);
+                       const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, const int32_t* partner,
+                       int P, const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream);
 
 /* Tree-GRU message passing — lib/combine_tree/cluster_tree.py:163-204
  * (forward_v1), 281-316 (bottom-up), 318-330 (top-down, 'tree' mode), for a

@@ -178,6 +178,14 @@ def test_pair_infer_fused_vs_reference_order():
     assert float((got2 - got).abs().max()) <= 2e-2 * float(ref.abs().max())
     vp_got = pooled[:, :, :D].float().cpu().permute(0, 2, 1).reshape(P, D, 7, 7)
     assert float((vp_got - vp).abs().max()) <= 1e-2 * float(vp.abs().max())
+    # ... and with swapped pairs sharing one pooled row: identical rows of sp
+    part_d = torch.from_numpy(part).to(DEV)
+    pooled_sh = ops.pair_pool(vab.to(DEV), torch.from_numpy(rel).to(DEV), 1 / 16., 7, partner=part_d)
+    lead = torch.from_numpy((part < 0) | (part > np.arange(P))).to(DEV)
+    assert torch.equal(pooled_sh[lead], pooled[lead])
+    sp3 = ops.pair_combine(pooled_sh, (B, H, W), qk, torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV),
+                           torch.from_numpy(Y).int().to(DEV), bias.to(DEV), 1 / 16., 7, partner=part_d)
+    assert torch.equal(sp3, sp2)
 
 
 @pytest.mark.parametrize("prd_k,topk", [(1, 100), (3, 100), (20, 50), (200, 7)])

@@ -63,8 +63,8 @@ SIGNATURES = {
     "trace_pair_attention_fused": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, c_float, c_int, c_int, P, P, P, P]),
     "trace_upload_slots": (c_int, [P, c_size_t, P, P, c_size_t, P]),
     "trace_pair_infer_fused": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, c_float, c_int, P, P]),
-    "trace_pair_pool": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, P, P]),
-    "trace_pair_combine": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, P, c_float, c_int, P, P]),
+    "trace_pair_pool": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_float, c_int, P, P]),
+    "trace_pair_combine": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, c_float, c_int, P, P]),
     "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                ctypes.POINTER(TreeGruWeights), c_int, P, P, P, P]),
 }

@@ -392,9 +392,14 @@ __device__ __forceinline__ void pa_geometry(const float* r, int B, float scale, 
 }
 
 __global__ __launch_bounds__(256) void pair_pool_kernel(const uint16_t* __restrict__ vab, int B, int H, int W, int D,
-                                                        const float* __restrict__ rel_rois, float scale, int PS,
+                                                        const float* __restrict__ rel_rois,
+                                                        const int32_t* __restrict__ partner, float scale, int PS,
                                                         uint16_t* __restrict__ pooled) {
   const int p = blockIdx.x;
+  if (partner) {   // swapped pairs share a union box: only the lower index pools (row p of `pooled`)
+    const int q = partner[p];
+    if (q >= 0 && q < p) return;
+  }
   const int cells = PS * PS;
   const int lpb = D >> 3, bpr = 256 / lpb;
   const int cg = threadIdx.x % lpb, slot = threadIdx.x / lpb;
@@ -446,9 +451,14 @@ __global__ __launch_bounds__(256) void pair_pool_kernel(const uint16_t* __restri
 __global__ __launch_bounds__(256) void pair_combine_kernel(
     const uint16_t* __restrict__ pooled, int B, int H, int W, int D, const float* __restrict__ qk, int ld_qk,
     const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
-    const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
+    const int32_t* __restrict__ partner, const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
   __shared__ float sc_s[PA_MAX_CELLS], sc_o[PA_MAX_CELLS];
   const int p = blockIdx.x;
+  int prow = p;            // row of `pooled` that holds this pair's union-box pooling
+  if (partner) {
+    const int q = partner[p];
+    if (q >= 0 && q < p) prow = q;
+  }
   const int cells = PS * PS;
   const int lpb = D >> 3, bpr = 256 / lpb;
   const int cg = threadIdx.x % lpb, slot = threadIdx.x / lpb;
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
   for (int cell0 = 0; cell0 < cells; cell0 += bpr) {
     const int cell = cell0 + slot;
     if (cell >= cells) break;
-    const uint16_t* src = pooled + ((long long)p * cells + cell) * (3 * D) + cg * 8;
+    const uint16_t* src = pooled + ((long long)prow * cells + cell) * (3 * D) + cg * 8;
     const uint4 v0 = *reinterpret_cast<const uint4*>(src);
     const uint4 v1 = *reinterpret_cast<const uint4*>(src + D);
     const uint4 v2 = *reinterpret_cast<const uint4*>(src + 2 * D);
@@ -1043,22 +1053,24 @@ extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, 
   return check_launch("pair_infer_fused");
 }
 
-extern "C" int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois, int P,
-                               float spatial_scale, int pooled, uint16_t* out, trace_stream_t stream) {
+extern "C" int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois,
+                               const int32_t* partner, int P, float spatial_scale, int pooled, uint16_t* out,
+                               trace_stream_t stream) {
   TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_pool: bad shape");
   TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_pool: D=%d must be 64/128/256/512", D);
   TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_pool: pooled=%d too large", pooled);
   if (P == 0) return 0;
   TRACE_REQUIRE(vab && rel_rois && out, "pair_pool: null pointer");
   TRACE_REQUIRE((((uintptr_t)vab | (uintptr_t)out) & 15) == 0, "pair_pool: vab / out must be 16-byte aligned");
-  hipLaunchKernelGGL(pair_pool_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, rel_rois, spatial_scale,
-                     pooled, out);
+  hipLaunchKernelGGL(pair_pool_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, rel_rois, partner,
+                     spatial_scale, pooled, out);
   return check_launch("pair_pool");
 }
 
 extern "C" int trace_pair_combine(const uint16_t* pooled_maps, int B, int H, int W, int D, const float* qk, int ld_qk,
-                                  const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds, int P,
-                                  const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream) {
+                                  const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds,
+                                  const int32_t* partner, int P, const float* bias, float spatial_scale, int pooled,
+                                  uint16_t* sp, trace_stream_t stream) {
   TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_combine: bad shape");
   TRACE_REQUIRE(D == 64 || D == 128 || D == 256 || D == 512, "pair_combine: D=%d must be 64/128/256/512", D);
   TRACE_REQUIRE(pooled * pooled <= PA_MAX_CELLS, "pair_combine: pooled=%d too large", pooled);
@@ -1067,7 +1079,7 @@ extern "C" int trace_pair_combine(const uint16_t* pooled_maps, int B, int H, int
   TRACE_REQUIRE(pooled_maps && qk && rel_rois && sbj_inds && obj_inds && bias && sp, "pair_combine: null pointer");
   TRACE_REQUIRE((((uintptr_t)pooled_maps | (uintptr_t)sp) & 15) == 0, "pair_combine: maps / sp must be 16-byte aligned");
   hipLaunchKernelGGL(pair_combine_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, pooled_maps, B, H, W, D, qk, ld_qk,
-                     rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled, sp);
+                     rel_rois, sbj_inds, obj_inds, partner, bias, spatial_scale, pooled, sp);
   return check_launch("pair_combine");
 }
 

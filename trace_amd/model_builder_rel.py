@@ -196,8 +196,11 @@ class Generalized_RCNN(nn.Module):
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
         self.share_swapped_pairs = True  # (s,o) and (o,s) have one union box: pooled once for both
-        self.split_pair_pool = False     # with side_stream: pool on the second stream, combine after the tree-GRU
-                                         # (measured no faster than the fused launch: 2.869 vs 2.852 ms/step)
+        # with side_stream: the union-box pooling of the pair kernel as its own launch on the second stream, only the
+        # query-dependent combine after the tree-GRU.  "tail": pooled beside the post-backbone chain (temporal object
+        # branch, tree-GRU, query GEMMs); True: beside the backbone (measured no faster than the fused launch: 2.869 vs
+        # 2.852 ms/step); False: one fused launch after the tree-GRU
+        self.split_pair_pool = "tail"
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -706,8 +709,9 @@ class Generalized_RCNN(nn.Module):
                     vmap = None
                     # with the second stream the union-box pooling (the heavy half of the pair kernel) runs here,
                     # beside the backbone; what depends on the queries is a streaming pass after the tree-GRU
-                    pa["pooled_vab"] = (ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps)
-                                        if self.side_stream and self.split_pair_pool else None)
+                    part_d = dv[ix["PART32"]] if self.share_swapped_pairs else None
+                    pa["pooled_vab"] = (ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps, partner=part_d)
+                                        if self.side_stream and self.split_pair_pool is True else None)
                 else:
                     vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
                 # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
@@ -767,6 +771,15 @@ class Generalized_RCNN(nn.Module):
                                                     ct3.temporal_r_atten_q_s, ct3.temporal_r_atten_q_o,
                                                     ct3.temporal_r_feat_val, "treg")
             r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
+            ev_r2c = None
+            if self.side_stream and self.fuse_pair_infer and self.split_pair_pool == "tail":
+                # the union-box pooling of the pair kernel depends on nothing computed after part A: it runs on the
+                # second stream beside the object temporal branch, the tree-GRU (32 workgroups) and the query GEMMs -
+                # a chain of small launches that leaves most CUs idle - and only the combine stays on the critical path
+                ev_r2c = torch.cuda.Event()
+                ev_r2c.record(side)
+                pa["pooled_vab"] = ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps,
+                                                 partner=dv[ix["PART32"]] if self.share_swapped_pairs else None)
         obj_agg, obj_agg_relu = temporal_branch(dv[ix["t_obj"]], det_feat, det_feat_bf, ct3.temporal_obj_fc,
                                                 ct3.temporal_obj_atten_q_s, ct3.temporal_obj_atten_q_o,
                                                 ct3.temporal_obj_feat_val, "tobj")
@@ -774,7 +787,10 @@ class Generalized_RCNN(nn.Module):
         # ---- temporal region features (:268-305): independent of the object branch (a chain of small,
         # latency-bound launches), so with `side_stream` the two chains run side by side
         if self.side_stream:
-            main.wait_stream(side)
+            if ev_r2c is not None:
+                main.wait_event(ev_r2c)
+            else:
+                main.wait_stream(side)
         # ---- tree message passing (:307-330)
         fc = ct3.feat_combine
         G = ct3.group_coeffi
@@ -801,8 +817,11 @@ class Generalized_RCNN(nn.Module):
             q_s, q_o = q_so[:, :low], q_so[:, low:]
             qk = ops.gemm_nt(q_so.view(2 * Ntot, low), kmap.view(-1, low), out_f32=True)   # (2*Ntot, B*h*w)
             if pa.get("pooled_vab") is not None:
+                if ev_r2c is not None:
+                    main.wait_stream(side)
                 sp = ops.pair_combine(pa["pooled_vab"], tuple(vab.shape[:3]), qk, union_d, dv[ix["X32"]], dv[ix["Y32"]],
-                                      bias_ab, cfg.REL_SPATIAL_SCALE, ps)
+                                      bias_ab, cfg.REL_SPATIAL_SCALE, ps,
+                                      partner=dv[ix["PART32"]] if self.share_swapped_pairs else None)
             else:
                 sp = ops.pair_infer(vab, qk, union_d, dv[ix["X32"]], dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps,
                                     partner=dv[ix["PART32"]] if self.share_swapped_pairs else None)

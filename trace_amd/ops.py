@@ -525,21 +525,32 @@ def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, poole
     return sp
 
 
-def pair_pool(vab, rel_rois, spatial_scale, pooled=7):
-    """Union-box pooling of vab (B,H,W,3D) bf16 -> (P, pooled*pooled, 3D) bf16 (first half of `pair_infer`)."""
+def _partner_ptr(partner, P, what):
+    if partner is None:
+        return None
+    L.require_gpu(partner)
+    if partner.dtype != torch.int32 or partner.numel() != P or not partner.is_contiguous():
+        raise RuntimeError(what + ": partner must be a contiguous int32 tensor with one entry per pair")
+    return L.ptr(partner)
+
+
+def pair_pool(vab, rel_rois, spatial_scale, pooled=7, partner=None):
+    """Union-box pooling of vab (B,H,W,3D) bf16 -> (P, pooled*pooled, 3D) bf16 (first half of `pair_infer`).  With
+    `partner` only the lower index of a swapped pair is pooled (the other row is left unwritten)."""
     vab = _bf16(vab, "vab")
     rel_rois = _f32(rel_rois)
     B, H, W, D3 = vab.shape
     P = rel_rois.shape[0]
     out = torch.empty((P, pooled * pooled, D3), dtype=torch.bfloat16, device=vab.device)
     with torch.cuda.device(vab.device):
-        L.check(L.lib().trace_pair_pool(L.ptr(vab), B, H, W, D3 // 3, L.ptr(rel_rois), P, float(spatial_scale), pooled,
-                                        L.ptr(out), L.stream()), "pair_pool")
+        L.check(L.lib().trace_pair_pool(L.ptr(vab), B, H, W, D3 // 3, L.ptr(rel_rois), _partner_ptr(partner, P, "pair_pool"),
+                                        P, float(spatial_scale), pooled, L.ptr(out), L.stream()), "pair_pool")
     return out
 
 
-def pair_combine(pooled_maps, map_shape, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7):
-    """Second half of `pair_infer`: pooled_maps (P, pooled*pooled, 3D) from `pair_pool`, map_shape = (B, H, W)."""
+def pair_combine(pooled_maps, map_shape, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7, partner=None):
+    """Second half of `pair_infer`: pooled_maps (P, pooled*pooled, 3D) from `pair_pool` (called with the same
+    `partner`), map_shape = (B, H, W)."""
     pooled_maps = _bf16(pooled_maps, "pooled_maps")
     rel_rois, bias = _f32(rel_rois), _f32(bias)
     L.require_gpu(sbj_inds, obj_inds, qk)
@@ -555,7 +566,8 @@ def pair_combine(pooled_maps, map_shape, qk, rel_rois, sbj_inds, obj_inds, bias,
     sp = torch.empty((P, cells, D), dtype=torch.bfloat16, device=pooled_maps.device)
     with torch.cuda.device(pooled_maps.device):
         L.check(L.lib().trace_pair_combine(L.ptr(pooled_maps), B, H, W, D, L.ptr(qk), qk.stride(0), L.ptr(rel_rois),
-                                           L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()), P, L.ptr(bias),
+                                           L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()),
+                                           _partner_ptr(partner, P, "pair_combine"), P, L.ptr(bias),
                                            float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_combine")
     return sp
 
