@@ -452,50 +452,64 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
     const uint16_t* __restrict__ pooled, int B, int H, int W, int D, const float* __restrict__ qk, int ld_qk,
     const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj, const int32_t* __restrict__ obj,
     const int32_t* __restrict__ partner, const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
-  __shared__ float sc_s[PA_MAX_CELLS], sc_o[PA_MAX_CELLS];
+  // with `partner`: the lower index of a swapped pair reads the shared pooled row ONCE and writes both rows of sp
+  __shared__ float sc_s[2][PA_MAX_CELLS], sc_o[2][PA_MAX_CELLS];
   const int p = blockIdx.x;
-  int prow = p;            // row of `pooled` that holds this pair's union-box pooling
-  if (partner) {
-    const int q = partner[p];
-    if (q >= 0 && q < p) prow = q;
-  }
   const int cells = PS * PS;
+  const bool share = partner != nullptr && cells <= 64;
+  int q = partner ? partner[p] : -1;
+  int prow = p;            // row of `pooled` that holds this pair's union-box pooling
+  if (q >= 0 && q < p) {
+    if (share) return;
+    prow = q;
+  }
+  const int npair = (share && q > p) ? 2 : 1;
   const int lpb = D >> 3, bpr = 256 / lpb;
   const int cg = threadIdx.x % lpb, slot = threadIdx.x / lpb;
   PGeom g;
   pa_geometry(rel_rois + (long long)p * 5, B, scale, PS, g);
   const float inv_count = 1.0f / (float)(g.grid_h * g.grid_w);
-  if (threadIdx.x < cells) {   // same summation order as pair_infer_kernel
-    const float* qs_row = qk + (long long)(2 * sbj[p]) * ld_qk + (long long)g.batch * H * W;
-    const float* qo_row = qk + (long long)(2 * obj[p] + 1) * ld_qk + (long long)g.batch * H * W;
-    const int cell = threadIdx.x;
-    const int ph = cell / PS, pw = cell - ph * PS;
-    float as = 0.f, ao = 0.f;
-    for (int iy = 0; iy < g.grid_h; ++iy)
-      for (int ix = 0; ix < g.grid_w; ++ix) {
-        PSample sm;
-        if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
+  {   // same summation order as pair_infer_kernel; wave 1 takes the swapped pair
+    const int which = threadIdx.x >> 6, cell = threadIdx.x & 63;
+    if (which < npair && cell < cells) {
+      const int pp = which ? q : p;
+      const float* qs_row = qk + (long long)(2 * sbj[pp]) * ld_qk + (long long)g.batch * H * W;
+      const float* qo_row = qk + (long long)(2 * obj[pp] + 1) * ld_qk + (long long)g.batch * H * W;
+      const int ph = cell / PS, pw = cell - ph * PS;
+      float as = 0.f, ao = 0.f;
+      for (int iy = 0; iy < g.grid_h; ++iy)
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          PSample sm;
+          if (!pa_sample(g, PS, H, W, ph, pw, iy, ix, sm)) continue;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          as += sm.w[c] * qs_row[sm.pos[c]];
-          ao += sm.w[c] * qo_row[sm.pos[c]];
+          for (int c = 0; c < 4; ++c) {
+            as += sm.w[c] * qs_row[sm.pos[c]];
+            ao += sm.w[c] * qo_row[sm.pos[c]];
+          }
         }
-      }
-    sc_s[cell] = as * inv_count;
-    sc_o[cell] = ao * inv_count;
+      sc_s[which][cell] = as * inv_count;
+      sc_o[which][cell] = ao * inv_count;
+    }
   }
   __syncthreads();
-  float ms = -__builtin_inff(), mo = -__builtin_inff();
-  for (int c = 0; c < cells; ++c) {
-    ms = fmaxf(ms, sc_s[c]);
-    mo = fmaxf(mo, sc_o[c]);
+  float ms[2], mo[2], is[2], io[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    ms[k] = mo[k] = -__builtin_inff();
+    is[k] = io[k] = 0.f;
+    if (k >= npair) continue;
+    for (int c = 0; c < cells; ++c) {
+      ms[k] = fmaxf(ms[k], sc_s[k][c]);
+      mo[k] = fmaxf(mo[k], sc_o[k][c]);
+    }
+    float ss = 0.f, so = 0.f;
+    for (int c = 0; c < cells; ++c) {
+      ss += expf(sc_s[k][c] - ms[k]);
+      so += expf(sc_o[k][c] - mo[k]);
+    }
+    is[k] = 1.0f / ss;
+    io[k] = 1.0f / so;
   }
-  float ss = 0.f, so = 0.f;
-  for (int c = 0; c < cells; ++c) {
-    ss += expf(sc_s[c] - ms);
-    so += expf(sc_o[c] - mo);
-  }
-  const float is = 1.0f / ss, io = 1.0f / so;
   float bv[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bv[j] = bias[cg * 8 + j];
@@ -509,25 +523,29 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
     const uint32_t* u0 = &v0.x;
     const uint32_t* u1 = &v1.x;
     const uint32_t* u2 = &v2.x;
-    const float ws = expf(sc_s[cell] - ms) * is, wo = expf(sc_o[cell] - mo) * io;
-    float o[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float vl = __uint_as_float(u0[j] << 16), vh = __uint_as_float(u0[j] & 0xffff0000u);
-      const float al = __uint_as_float(u1[j] << 16), ah = __uint_as_float(u1[j] & 0xffff0000u);
-      const float bl = __uint_as_float(u2[j] << 16), bh = __uint_as_float(u2[j] & 0xffff0000u);
-      float t0 = ws * al + wo * bl + bv[2 * j], t1 = ws * ah + wo * bh + bv[2 * j + 1];
-      t0 = t0 > 0.f ? t0 : 0.1f * t0;
-      t1 = t1 > 0.f ? t1 : 0.1f * t1;
-      o[2 * j] = t0 + vl;
-      o[2 * j + 1] = t1 + vh;
+    for (int k = 0; k < 2; ++k) {
+      if (k >= npair) break;
+      const float ws = expf(sc_s[k][cell] - ms[k]) * is[k], wo = expf(sc_o[k][cell] - mo[k]) * io[k];
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float vl = __uint_as_float(u0[j] << 16), vh = __uint_as_float(u0[j] & 0xffff0000u);
+        const float al = __uint_as_float(u1[j] << 16), ah = __uint_as_float(u1[j] & 0xffff0000u);
+        const float bl = __uint_as_float(u2[j] << 16), bh = __uint_as_float(u2[j] & 0xffff0000u);
+        float t0 = ws * al + wo * bl + bv[2 * j], t1 = ws * ah + wo * bh + bv[2 * j + 1];
+        t0 = t0 > 0.f ? t0 : 0.1f * t0;
+        t1 = t1 > 0.f ? t1 : 0.1f * t1;
+        o[2 * j] = t0 + vl;
+        o[2 * j + 1] = t1 + vh;
+      }
+      uint4 pk;
+      pk.x = pack_bf16x2(o[0], o[1]);
+      pk.y = pack_bf16x2(o[2], o[3]);
+      pk.z = pack_bf16x2(o[4], o[5]);
+      pk.w = pack_bf16x2(o[6], o[7]);
+      *reinterpret_cast<uint4*>(sp + ((long long)(k ? q : p) * cells + cell) * D + cg * 8) = pk;
     }
-    uint4 pk;
-    pk.x = pack_bf16x2(o[0], o[1]);
-    pk.y = pack_bf16x2(o[2], o[3]);
-    pk.z = pack_bf16x2(o[4], o[5]);
-    pk.w = pack_bf16x2(o[6], o[7]);
-    *reinterpret_cast<uint4*>(sp + ((long long)p * cells + cell) * D + cg * 8) = pk;
   }
 }
 
