@@ -4,6 +4,7 @@
 //   fused pair attention lib/modeling_rel/model_builder_rel.py:1524-1612
 //   tree-GRU             lib/combine_tree/cluster_tree.py:163-204, 281-330
 #include "common.h"
+#include <stdlib.h>
 
 namespace trace {
 
@@ -739,7 +740,7 @@ __device__ __forceinline__ float dot_lds(const float* __restrict__ Wt, int Hd, i
 }
 
 template <int CF, int CH>
-__global__ __launch_bounds__(256) void tree_gru_lds_kernel(const TreeParams p, int nn_max) {
+__global__ __launch_bounds__(512) void tree_gru_lds_kernel(const TreeParams p, int nn_max) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int t = blockIdx.x, g = blockIdx.y;
   const TreeW& w = p.w[g];
@@ -1155,11 +1156,18 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
         TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr2 = true;
       }
+      // the pass is a chain of ~4 x levels barrier-separated phases of (nodes of a level) x Hd outputs: more waves per
+      // workgroup = fewer rounds per phase (TRACE_TREE_THREADS: A/B measurements)
+      static const int tree_threads = [] {
+        const char* e = getenv("TRACE_TREE_THREADS");
+        const int v = e ? atoi(e) : 512;
+        return (v == 256 || v == 512) ? v : 512;   // 1024 would cap the kernel at 128 VGPRs (spills)
+      }();
       if (F == 64 && Hd == 64)
-        hipLaunchKernelGGL((tree_gru_lds_kernel<64, 64>), dim3(n_trees, n_groups), dim3(256), need,
+        hipLaunchKernelGGL((tree_gru_lds_kernel<64, 64>), dim3(n_trees, n_groups), dim3(tree_threads), need,
                            (hipStream_t)stream, p, max_tree_nodes);
       else
-        hipLaunchKernelGGL((tree_gru_lds_kernel<0, 0>), dim3(n_trees, n_groups), dim3(256), need,
+        hipLaunchKernelGGL((tree_gru_lds_kernel<0, 0>), dim3(n_trees, n_groups), dim3(tree_threads), need,
                            (hipStream_t)stream, p, max_tree_nodes);
       return check_launch("tree_gru");
     }
