@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--objects", type=int, default=20)
     ap.add_argument("--pipeline", type=int, default=1,
                     help="captured step graphs in flight per GPU (2 measured no faster than 1: 2634 vs 2653 clips/s)")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: a step's post-backbone chain runs beside the next step's backbone (model.overlap_steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch events (roofline leg)")
     return ap.parse_args()
@@ -100,6 +102,9 @@ def main():
     model.graph_step = True     # serving mode: the whole step replays from one HIP graph per step signature
     model.side_stream = True    # the HBM-bound weight-streaming FCs run on a second stream beside the backbone (-2 %)
     model.pipeline = args.pipeline   # step graphs in flight (2: the head of step i overlaps the backbone of step i+1)
+    # software-pipelined step graphs: call n runs the backbone of step n beside the rest of step n-1 and returns the
+    # results of step n-1; every timed region below ends with flush_steps(), so K calls = K complete steps
+    model.overlap_steps = bool(args.overlap) and args.pipeline == 1
     calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
     model.Prd_RCNN.calibrate_bn(calib.to(dev))       # setup only: sane activations for random weights
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -124,6 +129,8 @@ def main():
     state["resident"] = True
     for _ in range(args.pipeline):
         outs = step()
+    if model.overlap_steps:
+        outs = model.flush_steps()
     model.sync_steps()
     torch.cuda.synchronize()
     if dist:
@@ -132,6 +139,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         outs = step()
+    if model.overlap_steps:
+        outs = model.flush_steps()        # the last step's tail: inside the timed region
     model.sync_steps()
     torch.cuda.synchronize()
     if dist:

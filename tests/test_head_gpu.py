@@ -165,6 +165,55 @@ def test_step_graph_replay_equals_eager(setup):
         m._step_graphs.clear()
 
 
+def test_overlapped_steps_equal_step_graph(setup):
+    """`overlap_steps`: a call replays [backbone + part A of this step] beside [the rest of the previous step] and
+    returns the previous step's results; `flush_steps()` returns the last ones.  They must equal the plain step
+    graph's, over same-signature sequences and across a signature change (which flushes)."""
+    from trace_amd.synthetic import make_inputs
+    m = setup
+    m.to(DEV)
+    a = make_inputs(2, 8, 6, 224, seed=21)
+    b = make_inputs(2, 8, 6, 224, seed=22)
+    c = (a[0], a[1], a[2], [a[3][0], a[3][1][:4]])
+    seq = [a, b, a, b, b, c, c, a]
+    keys = ("prd_scores", "det_labels", "msp_det_scores", "top_scores", "top_pair", "top_prd", "sbj_labels", "obj_scores")
+
+    def run(case):
+        fr, bl, fe, ro = case
+        return m(fr.to(DEV), bl.to(DEV), fe.to(DEV), ro, topk=50, prd_k=2)
+
+    def snap(outs):
+        torch.cuda.synchronize()
+        return [{k: o[k].clone() for k in keys} for o in outs]
+
+    try:
+        for side in (False, True):
+            m.side_stream, m.graph_step, m.overlap_steps = side, True, False
+            m._step_graphs.clear()
+            m._ov_graphs.clear()
+            want = [snap(run(case)) for case in seq]
+            m.overlap_steps = True
+            got = []
+            for case in seq:
+                outs = run(case)
+                if outs is not None:
+                    got.append(snap(outs))
+            got.append(snap(m.flush_steps()))
+            assert m.flush_steps() is None
+            assert len(got) == len(want)
+            for i, (g, w) in enumerate(zip(got, want)):
+                for og, ow in zip(g, w):
+                    for k in keys:
+                        assert torch.equal(og[k], ow[k]), (side, i, k)
+    finally:
+        m.flush_steps()
+        m.overlap_steps = False
+        m.graph_step = False
+        m.side_stream = False
+        m._step_graphs.clear()
+        m._ov_graphs.clear()
+
+
 def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=False, **okw):
     """Shared checker: pair lists identical, logits rel-L2 < 2e-2, relation scores atol 2e-2, top-100 per
     check_topk (with thousands of candidates and synthetic weights the scores around rank 100 are spaced

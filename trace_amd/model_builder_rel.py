@@ -184,6 +184,13 @@ class Generalized_RCNN(nn.Module):
         self.graph_step = False
         self._step_graphs = {}
         self._last_step_entry = None
+        # graph_step only: a call captures / replays [backbone + part A of THIS step] beside [the rest of the PREVIOUS
+        # step] - the post-backbone chain is ~45 small dependent launches that leave the chip idle - and returns the
+        # previous step's results (None on the first call); `flush_steps()` finishes the pending step
+        self.overlap_steps = False
+        self._ov_graphs = {}
+        self._ov_pending = None
+        self._ov_last = None
         self._pk_epoch = 0
         self._side_streams = {}
         self.side_stream = False
@@ -362,6 +369,10 @@ class Generalized_RCNN(nn.Module):
             dev = all_frames.device
             prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale,
                                    det_labels, det_scores)
+            if self.graph_step and self.overlap_steps and ops.IGEMM_TRACE is None:
+                return self._replay_overlap(all_frames, blob_conv, feat_map, prep, topk, prd_k)
+            if self._ov_pending is not None:
+                raise RuntimeError("a step is pending in the overlapped pipeline: call flush_steps() first")
             if self.graph_step and ops.IGEMM_TRACE is None:
                 res = self._replay_step(all_frames, blob_conv, feat_map, prep, topk, prd_k)
             else:
@@ -456,6 +467,121 @@ class Generalized_RCNN(nn.Module):
         self._last_step_entry = ent
         return ent["res"]
 
+    # ------------------------------------------------------------------ software-pipelined step graphs
+    def _replay_overlap(self, all_frames, blob_conv, feat_map, prep, topk, prd_k):
+        """`overlap_steps`: two captured graphs per step signature alternate.  Graph w uploads the packed host arrays
+        of step n into buffer w, runs the backbone + part A of step n (outputs = hand-off set w) and, on a forked
+        branch with its own split-K scratch, the rest of step n-1 from hand-off set 1-w.  Graph 0 is captured first,
+        so its tail reads a static copy that graph 1 fills after its part A; graph 1's tail reads graph 0's outputs
+        in place.  Returns the per-clip dicts of step n-1 (None when nothing was pending)."""
+        dev = all_frames.device
+        key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
+               feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
+               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs)
+        flushed = None
+        if self._ov_pending is not None and self._ov_pending["key"] != key:
+            flushed = self.flush_steps()          # another step signature: no graph holds that pair of steps
+        ent = self._ov_graphs.get(key)
+        cur = torch.cuda.current_stream(dev)
+        if ent is None:
+            frames_s = all_frames.detach().clone(memory_format=torch.contiguous_format)
+            blob_s, fmap_s = self._nhwc(blob_conv).clone(), self._nhwc(feat_map).clone()
+            nb = (max(prep["upl"].nbytes, 256) + 255) // 256 * 256
+            nreal = max(prep["upl"].nbytes, 256)
+            var = []
+            for w in range(2):
+                var.append(dict(dv=torch.empty((nb,), dtype=torch.uint8, device=dev),
+                                pinned=torch.zeros((2 * nb,), dtype=torch.uint8, pin_memory=True),
+                                counter=torch.zeros((2,), dtype=torch.int32, device=dev), seq=0, events=[None, None]))
+                var[w]["pinned_np"] = var[w]["pinned"].numpy()
+            torch.cuda.synchronize(dev)
+            prep["upl"].commit(dev, into=var[0]["dv"][:nreal])
+            var[1]["dv"].copy_(var[0]["dv"])
+            dvv = [prep["upl"].views(var[0]["dv"]), prep["upl"].views(var[1]["dv"])]
+            warm = torch.cuda.Stream(device=dev)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm):        # packs weights, sizes workspaces, warms the allocator (both scratch bases)
+                static = self._device_forward(frames_s, blob_s, fmap_s, prep, dvv[1], topk, prd_k, False, phase="a")
+                with ops.workspace_base(2):
+                    self._device_forward(None, blob_s, fmap_s, prep, dvv[1], topk, prd_k, False, phase="b", hand=static)
+            cur.wait_stream(warm)
+            torch.cuda.synchronize(dev)
+            tail_stream = torch.cuda.Stream(device=dev)
+            graphs, hands, results = [], [None, static], []
+            for w in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    main = torch.cuda.current_stream(dev)
+                    # the upload is the graph's one root node: the tail (which needs nothing of this step) forks behind
+                    # it - forking from the still empty capture stream and forking again before any launch on the
+                    # branch crashed hipStreamEndCapture
+                    ops.upload_slots(var[w]["pinned"], nb, var[w]["counter"], var[w]["dv"], nb)
+                    tail_stream.wait_stream(main)
+                    with torch.cuda.stream(tail_stream), ops.workspace_base(2):
+                        res = self._device_forward(None, blob_s, fmap_s, prep, dvv[1 - w], topk, prd_k, False, phase="b",
+                                                   hand=hands[1 - w])
+                    out = self._device_forward(frames_s, blob_s, fmap_s, prep, dvv[w], topk, prd_k, False, phase="a")
+                    if w == 0:
+                        hands[0] = out
+                    else:
+                        for name, dst in static.items():               # graph 0 was captured against the static set
+                            if torch.is_tensor(dst):
+                                dst.copy_(out[name])
+                    main.wait_stream(tail_stream)
+                graphs.append(g)
+                results.append(res)
+            # the tail alone, for flush_steps(): one graph per hand-off set
+            fgraphs, fres = [], []
+            for w in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fres.append(self._device_forward(None, blob_s, fmap_s, prep, dvv[w], topk, prd_k, False, phase="b",
+                                                     hand=hands[w]))
+                fgraphs.append(g)
+            ent = self._ov_graphs[key] = dict(fgraphs=fgraphs, fres=fres,
+                                              graphs=graphs, hands=hands, res=results, var=var, dvv=dvv, frames=frames_s,
+                                              blob=blob_s, fmap=fmap_s, nbytes=prep["upl"].nbytes, slot_bytes=nb, n=0,
+                                              keep=(static, tail_stream))
+        if prep["upl"].nbytes != ent["nbytes"]:
+            raise RuntimeError("upload layout changed under a captured step")
+        w = ent["n"] & 1
+        v = ent["var"][w]
+        slot = v["seq"] & 1
+        ev = v["events"][slot]
+        if ev is not None:
+            ev.synchronize()                         # the replay that read this pinned slot has finished
+        prep["upl"].fill(v["pinned_np"][slot * ent["slot_bytes"]:(slot + 1) * ent["slot_bytes"]])
+        if all_frames.data_ptr() != ent["frames"].data_ptr():
+            ent["frames"].copy_(all_frames)
+        if blob_conv.data_ptr() != ent["blob"].data_ptr():
+            ent["blob"].copy_(self._nhwc(blob_conv))
+        if feat_map.data_ptr() != ent["fmap"].data_ptr():
+            ent["fmap"].copy_(self._nhwc(feat_map))
+        ent["graphs"][w].replay()
+        if ev is None:
+            ev = v["events"][slot] = torch.cuda.Event()
+        ev.record()
+        v["seq"] += 1
+        ent["n"] += 1
+        self._ov_last = ent
+        pend = self._ov_pending
+        outs = flushed
+        if pend is not None:
+            outs = self._make_outs(pend["prep"], ent["res"][w], topk, prd_k)
+        self._ov_pending = dict(key=key, ent=ent, w=w, prep=prep, topk=topk, prd_k=prd_k)
+        return outs
+
+    def flush_steps(self):
+        """Finish the step still pending in the overlapped pipeline (a captured graph of the tail alone, on the current
+        stream) and return its per-clip dicts; None when nothing is pending."""
+        pend = self._ov_pending
+        if pend is None:
+            return None
+        ent, w = pend["ent"], pend["w"]
+        ent["fgraphs"][w].replay()
+        self._ov_pending = None
+        return self._make_outs(pend["prep"], ent["fres"][w], pend["topk"], pend["prd_k"])
+
     def sync_steps(self):
         """Order the current stream behind every step still running on a pipeline stream (pipeline depth > 1)."""
         for ents in self._step_graphs.values():
@@ -467,6 +593,9 @@ class Generalized_RCNN(nn.Module):
         """(clip, blob_conv, feat_map) input buffers of the step-graph instance the NEXT call with the last step
         signature will replay: a loader that fills them in place (channels-last bf16 maps) saves the per-step
         copies.  With pipeline depth > 1 the instances alternate, so ask before every step."""
+        if self.overlap_steps and self._ov_last is not None:
+            e = self._ov_last
+            return e["frames"], e["blob"], e["fmap"]
         e = self._last_step_entry
         ents = e["owner"]
         nxt = ents["inst"][ents["calls"] % len(ents["inst"])]
@@ -628,12 +757,14 @@ class Generalized_RCNN(nn.Module):
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
                     sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False), max_tree_nodes=n + m)
 
-    def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone):
+    def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone, phase="all", hand=None):
         """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
-        whole of it can be captured into a HIP graph.  Returns flat tensors over all clips."""
+        whole of it can be captured into a HIP graph.  Returns flat tensors over all clips.
+        phase "a": stop after the backbone and part A and return what the rest of the step reads (`hand`: the
+        temporal maps + part A's outputs); phase "b": the rest of the step from such a `hand` (`overlap_steps`)."""
         cfg = self.cfg
-        dev = all_frames.device
-        B = all_frames.shape[0]
+        dev = blob.device
+        B = blob.shape[0]
         ps = self.pool_size
         D, low = cfg.MLP_HEAD_DIM, cfg.LOW_FEAT_DIM
         C = cfg.CONV_BODY_DIM
@@ -649,7 +780,10 @@ class Generalized_RCNN(nn.Module):
         # for every fork point between the stem and layer3; an early version of the head lost 10 % this way)
         main = torch.cuda.current_stream(dev)
         side = main
-        if self.side_stream:
+        # the tail of an overlapped step (phase "b") stays on ONE stream: it is hidden behind the next backbone anyway,
+        # and a branch that forks again inside the capture crashed hipStreamEndCapture (ROCm 7.2)
+        fork_b = self.side_stream and phase != "b"
+        if self.side_stream and phase != "b":
             side = self._side_streams.get(dev.index)
             if side is None:
                 side = self._side_streams[dev.index] = torch.cuda.Stream(device=dev)
@@ -730,15 +864,19 @@ class Generalized_RCNN(nn.Module):
                           so_bias=so_bias, so_part=so_part, n_rel=n_rel)
 
         # ---- I3D backbone (:978-981)
-        hook = None
-        if self.side_stream and not graph_backbone:
-            hook = (self.side_fork_stage, part_a)
+        if phase == "b":
+            pa = dict(hand)
+            tmaps = hand["tmaps"]
         else:
-            part_a()
-        if graph_backbone:
-            tmaps = self.Prd_RCNN.forward_ndhwc_graphed(all_frames, in_ntchw=True)
-        else:
-            tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True, stage_hook=hook)   # (B,T',h,w,2048) bf16
+            hook = None
+            if self.side_stream and not graph_backbone:
+                hook = (self.side_fork_stage, part_a)
+            else:
+                part_a()
+            if graph_backbone:
+                tmaps = self.Prd_RCNN.forward_ndhwc_graphed(all_frames, in_ntchw=True)
+            else:
+                tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True, stage_hook=hook)   # (B,T',h,w,2048) bf16
         det_labels, det_scores, det_feat, det_feat_bf = pa["det_labels"], pa["det_scores"], pa["det_feat"], pa["det_feat_bf"]
         reg_feat, reg_feat_bf, kmap, vmap, vab, bias_ab = (pa["reg_feat"], pa["reg_feat_bf"], pa["kmap"], pa["vmap"],
                                                            pa["vab"], pa["bias_ab"])
@@ -748,8 +886,12 @@ class Generalized_RCNN(nn.Module):
         if Tn != prep["Tn"]:
             raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))
         tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
-        if self.side_stream:
+        if self.side_stream and phase != "b":
             main.wait_stream(side)
+        if phase == "a":
+            out = dict(pa)
+            out["tmaps"] = tmaps
+            return out
 
         # ---- cluster_tree3d: temporal object features (:158-201)
         def temporal_branch(rois_d, cur_feat, cur_feat_bf, fc, q_s_l, q_o_l, val, tag):
@@ -764,9 +906,9 @@ class Generalized_RCNN(nn.Module):
             # cur_feat + value MLP (:201, :305); second output = the ReLU'd operand of o2c / r2c (:374-379)
             return self._gemm(v, tag + "_v3", [val[3]], out_f32=True, residual=cur_feat, out2="relu")
 
-        if self.side_stream:
+        if fork_b:
             side.wait_stream(main)
-        with torch.cuda.stream(side), ops.workspace_slot(1 if self.side_stream else 0):
+        with torch.cuda.stream(side), ops.workspace_slot(1 if fork_b else 0):
             reg_agg, reg_agg_relu = temporal_branch(dv[ix["t_reg"]], reg_feat, reg_feat_bf, ct3.temporal_r_fc,
                                                     ct3.temporal_r_atten_q_s, ct3.temporal_r_atten_q_o,
                                                     ct3.temporal_r_feat_val, "treg")
@@ -776,8 +918,9 @@ class Generalized_RCNN(nn.Module):
                 # the union-box pooling of the pair kernel depends on nothing computed after part A: it runs on the
                 # second stream beside the object temporal branch, the tree-GRU (32 workgroups) and the query GEMMs -
                 # a chain of small launches that leaves most CUs idle - and only the combine stays on the critical path
-                ev_r2c = torch.cuda.Event()
-                ev_r2c.record(side)
+                if fork_b:
+                    ev_r2c = torch.cuda.Event()
+                    ev_r2c.record(side)
                 pa["pooled_vab"] = ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps,
                                                  partner=dv[ix["PART32"]] if self.share_swapped_pairs else None)
         obj_agg, obj_agg_relu = temporal_branch(dv[ix["t_obj"]], det_feat, det_feat_bf, ct3.temporal_obj_fc,
@@ -786,7 +929,7 @@ class Generalized_RCNN(nn.Module):
         o2c = self._gemm(obj_agg_relu, "o2c", [ct3.o2c[1]], out_f32=True)
         # ---- temporal region features (:268-305): independent of the object branch (a chain of small,
         # latency-bound launches), so with `side_stream` the two chains run side by side
-        if self.side_stream:
+        if fork_b:
             if ev_r2c is not None:
                 main.wait_event(ev_r2c)
             else:
