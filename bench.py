@@ -10,12 +10,16 @@ BASELINE.json's metric is quoted on (configs[1]: VidVRD res101xi3d50 setting, 32
 batch 8 per GPU, 20 objects / 380 pairs per clip, bf16).  Clips shard across ranks with no data-path
 collective (weak scaling); the per-video top-100 triplet records are all-gathered (RCCL) once after
 the timed region, as the sweep does.  Inputs are resident in HBM before timing.
+The steps run software-pipelined (model.overlap_steps, --overlap 0 turns it off): call n launches the backbone
+of step n beside the post-backbone chain of step n-1; the pipeline is empty when the timed region starts and
+is flushed inside it, so the K timed calls are K complete steps (first backbone and last tail un-overlapped).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     - dominant kernel (bf16 MFMA implicit-GEMM family): algorithmic FLOPs / launch time,
                  measured with events on the launch stream over the same K steps re-run launch by launch
                  right after the timed region (the timed steps replay the backbone from a HIP graph)
   cpu_baseline - the CPU oracle (a port of the reference path) timed on the host cores (rank 0, N=1)
+  roofline_roi_align - the object-head ROIAlign call of the workload against the HBM roofline
 """
 import argparse
 import json
