@@ -208,6 +208,14 @@ int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, int Hp,
                            int Wo, int epilogue, void* out,
                            trace_stream_t stream);
 
+/* The same stem for TRACE's shape only (3 -> 64, k(5,7,7), pad (2,3,3), stride (st,2,2), Ho and Wo multiples of 16)
+ * reading the caller's f32 clip directly - (N,C,T,H,W), or (N,T,C,H,W) with in_ntchw, C <= 3 - instead of a padded
+ * channels-last bf16 copy: the kernel converts while it fills its LDS patch.  w is the (64, 5*7*8*4) bf16 matrix of
+ * trace_conv3d_stem_bf16 (kwp = 8, Cp = 4).  Output (N,To,Ho,Wo,64) bf16, identical to the two-launch path. */
+int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, int H, int W, int in_ntchw, const uint16_t* w,
+                            const float* bias, int st, int To, int Ho, int Wo, int epilogue, void* out,
+                            trace_stream_t stream);
+
 /* nn.MaxPool3d on channels-last bf16 (resnet3d.py:732-737; mmcv NonLocal3d
  * sub_sample pool).  Padding is implicit -inf as in torch. */
 int trace_maxpool3d_ndhwc_bf16(const uint16_t* in, int N, int Ti, int Hi,

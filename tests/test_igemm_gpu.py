@@ -85,6 +85,11 @@ def test_conv3d_stem_matches_strided_conv():
         out = ops.conv3d_stem(xp, wp, b.to(DEV), 5, 7, 8, (st, 2, 2), (To, 16, 16))
         got = out.float().permute(0, 4, 1, 2, 3).cpu()
         _close(got, ref[:, :, ::(st // 2)])
+        # the same kernel fed from the f32 clip (both clip layouts): bit-identical to the padded-copy path
+        out2 = ops.conv3d_stem_f32(clip.to(DEV), True, wp, b.to(DEV), st, (To, 16, 16))
+        assert torch.equal(out2, out)
+        out3 = ops.conv3d_stem_f32(clip.permute(0, 2, 1, 3, 4).contiguous().to(DEV), False, wp, b.to(DEV), st, (To, 16, 16))
+        assert torch.equal(out3, out)
 
 
 @pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024),

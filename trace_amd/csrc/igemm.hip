@@ -63,6 +63,8 @@ struct IgemmParams {
   int epi2;          // TRACE_EPI_RELU | TRACE_EPI_LEAKY applied to the second output only
   long long bs_bias; // blockIdx.z stride of `bias` (elements)
   int xcd_slices;    // 1: split-K slices are pinned to XCDs (ksplit % 8 == 0), see igemm3_bf16_kernel
+  const float* in_f32;  // stem16 only: the raw f32 clip (N,C,T,H,W) or (N,T,C,H,W) instead of the padded bf16 `in`
+  int f_C, f_T, f_H, f_W, f_ntchw;
   int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
 };
 
@@ -779,6 +781,10 @@ constexpr int ST_ASTAGE = 64 * 128;
 constexpr int ST_LDS = ST_PATCH + 3 * ST_ASTAGE;
 constexpr int ST_KSTEPS = (ST_KT * ST_KH + 1) / 2;  // 18 K-steps of two taps
 
+// F32IN: the patch is built from the caller's f32 clip (planar, unpadded) - converted to bf16, channel-padded to 4 and
+// written with ds_write_b128 in the same LDS image as the LDS-DMA path - so the clip never makes the round trip through
+// a padded channels-last bf16 copy (trace_clip_to_ndhwc_bf16: 154 MB read + 122 MB written per 8 clips, 73 us).
+template <bool F32IN>
 __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -798,7 +804,7 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
   const int r0 = th * 16, c0 = tw * 16;
 
   // ---- patch: chunk q of the flattened (frame, row, 16-byte chunk) list -> LDS byte q*16
-  {
+  if (!F32IN) {
     const long long row_b = (long long)p.Wi * 8, frame_b = (long long)p.Hi * row_b;
     const char* src0 = reinterpret_cast<const char*>(p.in) +
                        (((long long)n * p.Ti + (long long)to * p.st) * p.Hi + 2 * r0) * row_b + (long long)c0 * 16;
@@ -831,6 +837,57 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
   };
   issue_a(0, false);
   issue_a(1, false);
+  if (F32IN) {
+    // halo (2 frames, 3 rows, 3 pixels) and the over-run of the last round are zeros; a chunk = 2 pixels x (3 + 1) channels
+    const int T = p.f_T, H = p.f_H, W = p.f_W, C = p.f_C;
+    const long long plane = (long long)H * W;
+    const long long cstride = p.f_ntchw ? plane : (long long)T * plane;
+    // loads go out unconditionally from clamped (always valid) addresses, seven chunks (42 loads) per batch, and are
+    // zeroed afterwards where the chunk lies in the halo: a branch around a load makes the compiler wait for each one
+    constexpr int NR = (ST_CHUNKS + 255) / 256;   // 14
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float raw[NR / 2][2][3];
+      bool okc[NR / 2][2];
+#pragma unroll
+      for (int r7 = 0; r7 < NR / 2; ++r7) {
+        const int q = (half * (NR / 2) + r7) * 256 + tid;
+        const int f = q / (ST_PR * ST_PC);
+        const int rem = q - f * (ST_PR * ST_PC);
+        const int row = rem / ST_PC;
+        const int ch = rem - row * ST_PC;
+        const int t = to * p.st + f - 2, y = 2 * r0 + row - 3, x0 = 2 * c0 + 2 * ch - 3;
+        const bool ok = q < ST_CHUNKS && (unsigned)t < (unsigned)T && (unsigned)y < (unsigned)H;
+        const int tc = min(max(t, 0), T - 1), yc = min(max(y, 0), H - 1);
+        const float* base = p.in_f32 + (p.f_ntchw ? ((long long)n * T + tc) * C * plane : ((long long)n * C * T + tc) * plane) +
+                            (long long)yc * W;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int x = x0 + e;
+          okc[r7][e] = ok && (unsigned)x < (unsigned)W;
+          const int xc = min(max(x, 0), W - 1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) raw[r7][e][c] = base[(c < C ? c : 0) * cstride + xc];
+        }
+      }
+#pragma unroll
+      for (int r7 = 0; r7 < NR / 2; ++r7) {
+        const int q = (half * (NR / 2) + r7) * 256 + tid;
+        float v[2][3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[e][c] = (okc[r7][e] && c < C) ? raw[r7][e][c] : 0.f;
+        uint4 o;
+        o.x = pack_bf16x2(v[0][0], v[0][1]);
+        o.y = pack_bf16x2(v[0][2], 0.f);
+        o.z = pack_bf16x2(v[1][0], v[1][1]);
+        o.w = pack_bf16x2(v[1][2], 0.f);
+        *reinterpret_cast<uint4*>(smem + q * 16) = o;
+      }
+    }
+    __syncthreads();
+  }
 
   f32x4 acc[2][8];
 #pragma unroll
@@ -1847,16 +1904,61 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
     // TRACE's stem shape: LDS-resident input patch (stem16_bf16_kernel); anything else takes the generic loop
     static bool attr_done = false;
     if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
       attr_done = true;
     }
     const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
     TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem: grid too large");
-    hipLaunchKernelGGL(stem16_bf16_kernel, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(stem16_bf16_kernel<false>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
     return check_launch("conv3d_stem16");
   }
   return launch_igemm(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, int H, int W, int in_ntchw,
+                                       const uint16_t* w, const float* bias, int st, int To, int Ho, int Wo, int epilogue,
+                                       void* out, trace_stream_t stream) {
+  TRACE_REQUIRE(N >= 0 && C >= 1 && C <= 3 && T > 0 && H > 0 && W > 0 && st > 0, "conv3d_stem16_f32: bad shape");
+  TRACE_REQUIRE(Ho > 0 && Wo > 0 && To > 0 && Ho % 16 == 0 && Wo % 16 == 0, "conv3d_stem16_f32: Ho, Wo must be multiples of 16");
+  TRACE_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1 && (To - 1) * st + 5 <= T + 4,
+                "conv3d_stem16_f32: output (%d,%d,%d) does not match a 5x7x7 / pad (2,3,3) / stride (%d,2,2) conv of (%d,%d,%d)",
+                To, Ho, Wo, st, T, H, W);
+  TRACE_REQUIRE(!(epilogue & (TRACE_EPI_OUT_F32 | TRACE_EPI_RESIDUAL)), "conv3d_stem16_f32: bf16 output, no residual");
+  long long M = (long long)N * To * Ho * Wo;
+  TRACE_REQUIRE(M < 0x7fffffffLL, "conv3d_stem16_f32: too many output positions");
+  if (M == 0) return 0;
+  TRACE_REQUIRE(clip && w && out, "conv3d_stem16_f32: null pointer");
+  TRACE_REQUIRE((((uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15) == 0 && ((uintptr_t)clip & 3) == 0,
+                "conv3d_stem16_f32: pointers misaligned");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in_f32 = clip;
+  p.f_C = C; p.f_T = T; p.f_H = H; p.f_W = W; p.f_ntchw = in_ntchw ? 1 : 0;
+  p.w = w;
+  p.bias = bias;
+  p.out = out;
+  p.M = (int)M;
+  p.Cout = 64;
+  p.Crun = 32;
+  p.Ktot = ST_KT * ST_KH * 32;
+  p.To = To; p.Ho = Ho; p.Wo = Wo;
+  p.kt = ST_KT; p.kh = ST_KH; p.kw = 1;
+  p.st = st; p.sh = 2; p.sw = 2;
+  p.ldw = p.Ktot;
+  p.ldo = 64;
+  p.alpha = 1.0f;
+  p.epi = epilogue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
+    attr_done = true;
+  }
+  const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
+  TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem16_f32: grid too large");
+  hipLaunchKernelGGL(stem16_bf16_kernel<true>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+  return check_launch("conv3d_stem16_f32");
 }
 
 static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda, int ldb, int ldc, int batch,

@@ -219,6 +219,28 @@ def clip_to_ndhwc(x, in_ntchw, Cp, pads=(0, 0, 0, 0, 0, 0)):
     return out
 
 
+def conv3d_stem_f32(x, in_ntchw, w, bias, stride_t, out_thw, relu=True):
+    """TRACE's stem (3 -> 64, 5x7x7, pad (2,3,3), stride (stride_t,2,2)) straight from the f32 clip x (N,C,T,H,W) or
+    (N,T,C,H,W): no padded bf16 copy of the clip.  w (64, 5*7*8*4) bf16 as for `conv3d_stem`."""
+    x = _f32(x, "clip")
+    w = _bf16(w, "w")
+    if in_ntchw:
+        N, T, C, H, W = x.shape
+    else:
+        N, C, T, H, W = x.shape
+    To, Ho, Wo = out_thw
+    if w.shape != (64, 5 * 7 * 8 * 4):
+        raise RuntimeError("conv3d_stem_f32: weight shape %s" % (tuple(w.shape),))
+    out = torch.empty((N, To, Ho, Wo, 64), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    with torch.cuda.device(x.device), _span(2.0 * out.numel() * 5 * 7 * 7 * C, 4 * x.numel() + 2 * (w.numel() + out.numel())):
+        L.check(L.lib().trace_conv3d_stem16_f32(L.ptr(x), N, C, T, H, W, int(bool(in_ntchw)), L.ptr(w), L.ptr(bias),
+                                                int(stride_t), To, Ho, Wo, EPI_RELU if relu else 0, L.ptr(out), L.stream()),
+                "conv3d_stem_f32")
+    return out
+
+
 def _out_size(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 

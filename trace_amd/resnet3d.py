@@ -310,6 +310,7 @@ class ResNet3d(nn.Module):
 
     # -- stem ---------------------------------------------------------------
     CP = 4  # clip channels padded 3 -> 4 (8-byte pixels)
+    stem_from_f32 = True   # TRACE's stem shape reads the f32 clip directly (ops.conv3d_stem_f32); False: padded bf16 copy first
 
     def _stem_weights(self):
         if self._stem_packed is None:
@@ -346,6 +347,12 @@ class ResNet3d(nn.Module):
         pw1 = max(need_w - (W + pw), pw)
         if (W + pw + pw1) % 2:
             pw1 += 1
+        st = self.conv1_stride_t * self.pool1_stride_t
+        if (self.stem_from_f32 and (kt, kh, kw) == (5, 7, 7) and kwp == 8 and self.CP == 4 and w.shape[0] == 64 and
+                Ho % 16 == 0 and Wo % 16 == 0 and x.dtype == torch.float32):
+            # the stem kernel converts the f32 clip while it fills its LDS patch: no padded bf16 copy of the clip
+            y = ops.conv3d_stem_f32(x, in_ntchw, w, b, st, (To, Ho, Wo))
+            return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
         xp = ops.clip_to_ndhwc(x, in_ntchw, self.CP, (pt, pt, ph, ph, pw, pw1))
         y = ops.conv3d_stem(xp, w, b, kt, kh, kwp, (self.conv1_stride_t * self.pool1_stride_t, 2, 2), (To, Ho, Wo),
                             alg_k=kt * kh * kw * C)
