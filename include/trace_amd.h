@@ -170,6 +170,9 @@ int trace_clip_to_ndhwc_bf16(const float* in, int N, int C, int T, int H,
 #define TRACE_EPI_LEAKY 8    /* LeakyReLU(0.1) instead of ReLU               */
 #define TRACE_EPI_RES_POST 16 /* add `residual` AFTER the activation          */
 #define TRACE_EPI_RES_F32 32 /* `residual` is f32, not bf16 (trace_gemm_bf16_nt_ex) */
+#define TRACE_EPI_POOL_T2 128 /* trace_conv3d_igemm_bf16, 1x1x1 stride-1 convs, even To: the epilogue also applies the
+                               * MaxPool3d((2,1,1), stride (2,1,1)) that follows layer1 (resnet3d.py:270, :798): out is
+                               * (N,To/2,Ho,Wo,Cout); residual keeps the unpooled shape.  Identical to conv + pool. */
 #define TRACE_EPI_WTILED 64  /* trace_gemm_bf16_nt*: Bm is PRE-TILED for weight streaming (N % 128 == 0, K % 64 == 0,
                               * ldb == K): block (n/128, k/64) is 16 KiB contiguous, holding for row r = n % 128 and
                               * 16-byte chunk pc = 0..7 the 8 elements Bm[n][64*(k/64) + 8*(pc ^ (r & 7)) ..] at byte

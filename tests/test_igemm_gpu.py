@@ -62,6 +62,26 @@ def test_conv3d_igemm(case, fuse):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 4, 14, 14, 256), (1, 128, 2, 9, 11, 72), (3, 64, 8, 20, 20, 128)])
+@pytest.mark.parametrize("res", [False, True])
+def test_conv3d_pooled_epilogue_equals_conv_then_pool(shape, res):
+    """TRACE_EPI_POOL_T2: MaxPool3d((2,1,1)) inside the 1x1x1 conv's epilogue == conv, then the pool kernel."""
+    from trace_amd import ops
+    N, Cin, T, H, W, Cout = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((N, T, H, W, Cin), generator=g).bfloat16().to(DEV)
+    w = (torch.randn((Cout, Cin), generator=g) / Cin ** 0.5).bfloat16().to(DEV)
+    b = torch.randn((Cout,), generator=g).to(DEV)
+    r = torch.randn((N, T, H, W, Cout), generator=g).bfloat16().to(DEV) if res else None
+    want = ops.maxpool3d(ops.conv3d(x, w, b, (1, 1, 1), residual=r, relu=True), (2, 1, 1), (2, 1, 1))
+    got = ops.conv3d(x, w, b, (1, 1, 1), residual=r, relu=True, pool_t2=True)
+    assert got.shape == want.shape == (N, T // 2, H, W, Cout)
+    assert torch.equal(got, want)
+    # not eligible (3 frames): falls back to the two launches
+    x3 = x[:, :1].repeat(1, 3, 1, 1, 1).contiguous()
+    assert ops.conv3d(x3, w, b, (1, 1, 1), relu=True, pool_t2=True).shape[1] == 1
+
+
 def test_conv3d_stem_matches_strided_conv():
     """Stem: 3->64, k(5,7,7), s(2,2,2), p(2,3,3) on the halo-padded clip, incl. the folded
     temporal stride 4 (= conv stride 2 followed by the pool's frame skipping)."""

@@ -63,6 +63,7 @@ struct IgemmParams {
   int epi2;          // TRACE_EPI_RELU | TRACE_EPI_LEAKY applied to the second output only
   long long bs_bias; // blockIdx.z stride of `bias` (elements)
   int xcd_slices;    // 1: split-K slices are pinned to XCDs (ksplit % 8 == 0), see igemm3_bf16_kernel
+  int pool_t2;       // 1 (dense 128x128 tiles only): the epilogue max-pools frame pairs (MaxPool3d (2,1,1)/(2,1,1)), see igemm3
   const float* in_f32;  // stem16 only: the raw f32 clip (N,C,T,H,W) or (N,T,C,H,W) instead of the padded bf16 `in`
   int f_C, f_T, f_H, f_W, f_ntchw;
   int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
@@ -593,10 +594,20 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   unsigned bmask[WN];      // conv: bit `tap` set <=> that tap of this position lies inside the input
   int tap = 0, tap_left = 0x7fffffff;
   int ta = 0, tb = 0, tcw = 0;
+  // pool_t2 (WN == 4): a tile is 64 POOLED positions; wave column wn holds pooled positions 32 wn .. + 32 twice -
+  // fragments 0, 1 from the even frame, fragments 2, 3 from the odd one - so the pair to be max-ed sits in ONE lane
+  const bool pool2 = DENSE && WN == 4 && p.pool_t2;
+  const int HW = p.Ho * p.Wo;
   if (DENSE) {
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
-      const int m = min(pos0 + lrow + 32 * i, p.M - 1);
+      int m = pos0 + lrow + 32 * i;
+      if (pool2) {
+        const int r = lrow + 32 * i;
+        const int pp = min((pos0 >> 1) + (r >> 6) * 32 + ((r >> 4) & 1) * 16 + (r & 15), (p.M >> 1) - 1);
+        m = pp + (pp / HW + ((r >> 5) & 1)) * HW;
+      }
+      m = min(m, p.M - 1);
       bp[i] = reinterpret_cast<const char*>(gin + (long long)m * p.pix + klin0);
     }
   } else {
@@ -755,6 +766,65 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     for (int st = 0; st < NST; ++st) step(st);
   }
   for (int st = 0; ks < ksteps; ++st) step(st);
+  if (pool2) {
+    if constexpr (WN == 4) {
+      // out[pp] = max over the frame pair of act(conv + bias (+ residual)); bf16 rounding is monotonic, so this equals
+      // the max-pool of the rounded conv output
+      const bool relu = p.epi & TRACE_EPI_RELU;
+      const bool has_res = (p.epi & TRACE_EPI_RESIDUAL) && p.res;
+      const int Mp = p.M >> 1;
+      uint16_t* outp = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll
+      for (int q = 0; q < WM / 2; ++q) {
+        const int c = cout0 + wm * (16 * WM) + fq * 8 + q * 32;
+        if (c >= p.Cout) continue;
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c);
+          const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c + 4);
+          bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w;
+          bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const int pp = (pos0 >> 1) + wn * 32 + jj * 16 + fr;
+          if (pp >= Mp) continue;
+          const long long m0 = pp + (long long)(pp / HW) * HW;
+          float best[8];
+#pragma unroll
+          for (int par = 0; par < 2; ++par) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[2 * q][jj + 2 * par][r] * p.alpha + bv[r];
+              v[4 + r] = acc[2 * q + 1][jj + 2 * par][r] * p.alpha + bv[4 + r];
+            }
+            if (has_res) {
+              const uint4 rv = *reinterpret_cast<const uint4*>(p.res + (m0 + (long long)par * HW) * p.ldo + c);
+              const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[2 * r] += __uint_as_float(rw[r] << 16);
+                v[2 * r + 1] += __uint_as_float(rw[r] & 0xffff0000u);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              if (relu) v[r] = fmaxf(v[r], 0.f);
+              best[r] = par ? fmaxf(best[r], v[r]) : v[r];
+            }
+          }
+          uint4 ov;
+          ov.x = pack_bf16x2(best[0], best[1]);
+          ov.y = pack_bf16x2(best[2], best[3]);
+          ov.z = pack_bf16x2(best[4], best[5]);
+          ov.w = pack_bf16x2(best[6], best[7]);
+          *reinterpret_cast<uint4*>(outp + (long long)pp * p.ldo + c) = ov;
+        }
+      }
+    }
+    return;
+  }
   igemm_epilogue<WM, WN>(p, acc, cout0, pos0, wm, wn, fr, fq, kslice);
 }
 
@@ -1752,6 +1822,10 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     if (wg14 >= 200) return p.dh == 1 ? launch_sconv9<7, 1>(p, wg14, s) : launch_sconv9<7, 2>(p, wg14, s);
     if (wg8 >= 128) return p.dh == 1 ? launch_sconv9<4, 1>(p, wg8, s) : launch_sconv9<4, 2>(p, wg8, s);
   }
+  if (p.pool_t2) {   // checked by the entry point: dense, bf16 out, even To; 128 x 128 tiles, no split-K
+    p.ws = nullptr;
+    return launch_cfg<4, 4>(p, batch, s, t.nst, 1);
+  }
   if (p.w_tiled) {   // pre-tiled weights: 128-cout tiles of the v3 loop only
     if (!p.dense || p.Cout % 128 != 0 || p.Ktot % BK != 0 || g_force_v2) {
       set_error("gemm: TRACE_EPI_WTILED needs a dense problem with N %% 128 == 0 and K %% 64 == 0");
@@ -1857,7 +1931,14 @@ extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi
   p.ldw = p.Ktot;
   p.ldo = Cout;
   p.alpha = 1.0f;
-  p.epi = epilogue;
+  p.epi = epilogue & ~TRACE_EPI_POOL_T2;
+  if (epilogue & TRACE_EPI_POOL_T2) {
+    TRACE_REQUIRE(kt == 1 && kh == 1 && kw == 1 && st == 1 && sh == 1 && sw == 1 && pt == 0 && ph == 0 && pw == 0,
+                  "conv3d: TRACE_EPI_POOL_T2 needs a 1x1x1 stride-1 conv");
+    TRACE_REQUIRE(To % 2 == 0 && !(epilogue & (TRACE_EPI_OUT_F32 | TRACE_EPI_LEAKY | TRACE_EPI_RES_POST)) && !g_force_v2,
+                  "conv3d: TRACE_EPI_POOL_T2 needs an even frame count and a bf16 ReLU / linear epilogue");
+    p.pool_t2 = 1;
+  }
   p.ws = ((uintptr_t)workspace & 15) ? nullptr : workspace;
   p.ws_bytes = workspace_bytes;
   return launch_igemm(p, 1, (hipStream_t)stream);

@@ -10,6 +10,8 @@ launch (same role as a HIP graph, but launch-by-launch so the per-launch event t
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -245,9 +247,19 @@ def _out_size(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+EPI_POOL_T2 = 128
+
+
 def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), residual=None,
-           relu=False, out_f32=False):
-    """x (N,T,H,W,Cin) bf16; w (Cout, kt*kh*kw*Cin) bf16 tap-major; bias (Cout) f32 or None."""
+           relu=False, out_f32=False, pool_t2=False):
+    """x (N,T,H,W,Cin) bf16; w (Cout, kt*kh*kw*Cin) bf16 tap-major; bias (Cout) f32 or None.
+    pool_t2: also apply MaxPool3d((2,1,1), stride (2,1,1)) to the result - inside the conv's epilogue when it is a
+    1x1x1 stride-1 conv over an even number of frames (the frame pair never reaches HBM), as a second launch otherwise."""
+    if pool_t2:
+        fused = (tuple(ksize) == (1, 1, 1) and tuple(stride) == (1, 1, 1) and tuple(padding) == (0, 0, 0) and
+                 x.shape[1] % 2 == 0 and not out_f32 and os.environ.get("TRACE_NO_POOL_FUSE") is None)
+        if not fused:
+            return maxpool3d(conv3d(x, w, bias, ksize, stride, padding, dilation, residual, relu, out_f32), (2, 1, 1), (2, 1, 1))
     x = _bf16(x, "x")
     w = _bf16(w, "w")
     N, Ti, Hi, Wi, Cin = x.shape
@@ -259,16 +271,19 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
     Ho = _out_size(Hi, kh, stride[1], padding[1], dilation[1])
     Wo = _out_size(Wi, kw, stride[2], padding[2], dilation[2])
     epi = (EPI_RELU if relu else 0) | (EPI_RESIDUAL if residual is not None else 0) | (EPI_OUT_F32 if out_f32 else 0)
-    out = torch.empty((N, To, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    if pool_t2:
+        epi |= EPI_POOL_T2
+    out = torch.empty((N, To // 2 if pool_t2 else To, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16,
+                      device=x.device)
     if residual is not None:
         residual = _bf16(residual, "residual")
-        if residual.shape != out.shape:
-            raise RuntimeError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(out.shape)))
+        if tuple(residual.shape) != (N, To, Ho, Wo, Cout):
+            raise RuntimeError("residual shape %s != conv output shape %s" % (tuple(residual.shape), (N, To, Ho, Wo, Cout)))
     if bias is not None:
         bias = _f32(bias, "bias")
     ws = workspace(x.device)
     nbytes = 2 * (x.numel() + w.numel()) + out.numel() * out.element_size() + (2 * out.numel() if residual is not None else 0)
-    with torch.cuda.device(x.device), _span(2.0 * out.numel() * kt * kh * kw * Cin, nbytes):
+    with torch.cuda.device(x.device), _span(2.0 * N * To * Ho * Wo * Cout * kt * kh * kw * Cin, nbytes):
         L.check(L.lib().trace_conv3d_igemm_bf16(
             L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
             stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],

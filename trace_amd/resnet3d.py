@@ -72,12 +72,13 @@ class ConvModule(nn.Module):
             x = self.bn(x)
         return torch.relu(x) if self.with_activation else x
 
-    def run(self, x, residual=None, relu=None):
-        """x channels-last bf16 (N,T,H,W,Cin) -> (N,To,Ho,Wo,Cout) bf16."""
+    def run(self, x, residual=None, relu=None, pool_t2=False):
+        """x channels-last bf16 (N,T,H,W,Cin) -> (N,To,Ho,Wo,Cout) bf16 (To/2 frames with pool_t2, see ops.conv3d)."""
         w, b = self.packed()
         c = self.conv
         relu = self.with_activation if relu is None else relu
-        return ops.conv3d(x, w, b, c.kernel_size, c.stride, c.padding, c.dilation, residual=residual, relu=relu)
+        return ops.conv3d(x, w, b, c.kernel_size, c.stride, c.padding, c.dilation, residual=residual, relu=relu,
+                          pool_t2=pool_t2)
 
     def _apply(self, fn, *a, **k):
         self._packed = None
@@ -220,12 +221,16 @@ class Bottleneck3d(nn.Module):
         out = torch.relu(self.conv3(self.conv2(self.conv1(x))) + identity)
         return self.non_local_block(out) if self.non_local else out
 
-    def run(self, x):
+    def run(self, x, pool_t2=False):
+        """pool_t2: the MaxPool3d((2,1,1)) that follows this block (pool2 after layer1) rides in conv3's epilogue."""
         identity = x if self.downsample is None else self.downsample.run(x)
         out = self.conv2.run(self.conv1.run(x))
-        out = self.conv3.run(out, residual=identity, relu=True)  # resnet3d.py:306,313
+        fuse = pool_t2 and not self.non_local
+        out = self.conv3.run(out, residual=identity, relu=True, pool_t2=fuse)  # resnet3d.py:306,313
         if self.non_local:
             out = self.non_local_block.run(out)
+            if pool_t2:
+                out = ops.maxpool3d(out, (2, 1, 1), (2, 1, 1))
         return out
 
 
@@ -370,10 +375,10 @@ class ResNet3d(nn.Module):
             if stage_hook is not None and stage_hook[0] == -1:
                 stage_hook[1]()
             for i, name in enumerate(self.res_layers[:self.num_stages]):
-                for blk in getattr(self, name):
-                    x = blk.run(x)
-                if i == 0 and self.with_pool2:
-                    x = ops.maxpool3d(x, (2, 1, 1), (2, 1, 1))
+                blocks = list(getattr(self, name))
+                for bi, blk in enumerate(blocks):
+                    # pool2 (resnet3d.py:798-799) rides in the epilogue of layer1's last conv3
+                    x = blk.run(x, pool_t2=(i == 0 and self.with_pool2 and bi == len(blocks) - 1))
                 if stage_hook is not None and stage_hook[0] == i:
                     stage_hook[1]()
         return x
