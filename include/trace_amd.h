@@ -253,6 +253,14 @@ int trace_gemm_bf16_nt_ex(const uint16_t* A, const uint16_t* Bm, int M, int N, i
                           const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
                           void* workspace, size_t workspace_bytes, trace_stream_t stream);
 
+/* C = act([A | A2] Bm^T + bias (+ residual)): one GEMM over two activation matrices with the same M rows - K-steps
+ * below K1 read A (row stride lda), the rest A2 (lda2); Bm is (N, K1 + K2) row-major.  K1 and K2 multiples of 64.
+ * A Bottleneck3d whose downsample conv has stride 1 (resnet3d.py:292-318: relu(conv3(h) + downsample(x))) becomes one
+ * launch with Bm = [W3 | Wd]: the downsample output is neither written nor re-read as the residual. */
+int trace_gemm_bf16_nt_dual(const uint16_t* A, int lda, int K1, const uint16_t* A2, int lda2, int K2, const uint16_t* Bm,
+                            int ldb, int M, int N, int ldc, const float* bias, const void* residual, int epilogue, void* C,
+                            trace_stream_t stream);
+
 /* Launch-configuration override for the three entry points above, for the calling thread:
  * tile 1..9 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128, 128 x 256, 256 x 128, 256x256, 128 x 192,
  * 256 x 192), nst = LDS ring depth 2..4,

@@ -67,12 +67,25 @@ def test_i3d_forward_matches_oracle(T, HW):
     ref = i3d_forward(m.state_dict(), clip)
     emu = i3d_forward(m.state_dict(), clip, emulate_bf16=True)
     m.to(DEV)
-    out = m(clip.to(DEV)).cpu()
+    # the emulation stores (= rounds) the downsample branch like the unfused bottleneck does: compare it with that
+    # form; the default form (stride-1 downsample blocks as one two-source GEMM, one rounding fewer) is held to the
+    # fp32 bound and to the documented distance between two bf16 executions
+    from trace_amd.resnet3d import Bottleneck3d
+    Bottleneck3d.fuse_downsample = False
+    try:
+        out = m(clip.to(DEV)).cpu()
+    finally:
+        Bottleneck3d.fuse_downsample = True
     assert out.shape == ref.shape
     emax, el2 = rel_err(out, emu)
     assert el2 < 5e-2, ("vs bf16-emulating oracle", emax, el2)
     emax, el2 = rel_err(out, ref)
     assert el2 < 1.2e-1, ("vs fp32 oracle", emax, el2)
+    fused = m(clip.to(DEV)).cpu()
+    emax, el2 = rel_err(fused, ref)
+    assert el2 < 1.2e-1, ("fused downsample vs fp32 oracle", emax, el2)
+    emax, el2 = rel_err(fused, out)
+    assert el2 < 8.4e-2, ("fused vs unfused downsample", emax, el2)
 
 
 def test_i3d_stages_teacher_forced_rtol_2e2():

@@ -82,6 +82,24 @@ def test_conv3d_pooled_epilogue_equals_conv_then_pool(shape, res):
     assert ops.conv3d(x3, w, b, (1, 1, 1), relu=True, pool_t2=True).shape[1] == 1
 
 
+@pytest.mark.parametrize("shape", [(1000, 256, 64, 64), (6272, 384, 128, 192), (130, 72, 64, 128)])
+def test_gemm_nt_two_sources(shape):
+    """[A | A2] @ B^T (trace_gemm_bf16_nt_dual) against the fp32 product of the concatenated operands."""
+    from trace_amd import ops
+    M, N, K1, K2 = shape
+    g = torch.Generator().manual_seed(9)
+    wide = torch.randn((M, K1 + 32), generator=g).bfloat16().to(DEV)       # row-strided view as first source
+    a1 = wide[:, :K1]
+    a2 = torch.randn((M, K2), generator=g).bfloat16().to(DEV)
+    w = (torch.randn((N, K1 + K2), generator=g) / (K1 + K2) ** 0.5).bfloat16().to(DEV)
+    b = torch.randn((N,), generator=g).to(DEV)
+    got = ops.gemm_nt_dual(a1, a2, w, bias=b, relu=True).float().cpu()
+    ref = torch.relu(torch.cat([a1.float(), a2.float()], 1).cpu() @ w.float().cpu().t() + b.cpu())
+    _close(got, ref)
+    same = ops.gemm_nt(torch.cat([a1, a2], 1).contiguous(), w, bias=b, relu=True)
+    assert torch.equal(same.float().cpu(), got)
+
+
 def test_conv3d_stem_matches_strided_conv():
     """Stem: 3->64, k(5,7,7), s(2,2,2), p(2,3,3) on the halo-padded clip, incl. the folded
     temporal stride 4 (= conv stride 2 followed by the pool's frame skipping)."""

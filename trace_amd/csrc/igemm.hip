@@ -63,6 +63,8 @@ struct IgemmParams {
   int epi2;          // TRACE_EPI_RELU | TRACE_EPI_LEAKY applied to the second output only
   long long bs_bias; // blockIdx.z stride of `bias` (elements)
   int xcd_slices;    // 1: split-K slices are pinned to XCDs (ksplit % 8 == 0), see igemm3_bf16_kernel
+  const uint16_t* in2;  // dense GEMMs: second activation matrix - K-steps >= k_switch read row m of it (row stride pix2)
+  int pix2, k_switch;
   int pool_t2;       // 1 (dense 128x128 tiles only): the epilogue max-pools frame pairs (MaxPool3d (2,1,1)/(2,1,1)), see igemm3
   const float* in_f32;  // stem16 only: the raw f32 clip (N,C,T,H,W) or (N,T,C,H,W) instead of the padded bf16 `in`
   int f_C, f_T, f_H, f_W, f_ntchw;
@@ -590,6 +592,8 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     }
   }
   const char* bp[WN];
+  const char* bp2[WN];     // dense, two sources: the rows of the second one
+  int sw_left = (DENSE && p.in2) ? p.k_switch : 0x7fffffff;   // K-steps until the switch (uniform)
   long long boff[WN];      // conv: element offset of the receptive field's corner (+ this lane's k chunk)
   unsigned bmask[WN];      // conv: bit `tap` set <=> that tap of this position lies inside the input
   int tap = 0, tap_left = 0x7fffffff;
@@ -609,6 +613,9 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
       }
       m = min(m, p.M - 1);
       bp[i] = reinterpret_cast<const char*>(gin + (long long)m * p.pix + klin0);
+      // second source (K = [K1 | K2] over two activation matrices, e.g. conv3(h) + downsample(x) of a bottleneck as
+      // one GEMM): the same rows of `in2`, taken over from K-step k_switch on
+      bp2[i] = p.in2 ? reinterpret_cast<const char*>(p.in2 + (long long)m * p.pix2 + kseg * 8) : nullptr;
     }
   } else {
     const int ntaps = p.kt * p.kh * p.kw;
@@ -702,6 +709,9 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     }
     if (!DENSE) {
       if (--tap_left == 0) next_tap();
+    } else if (--sw_left == 0) {
+#pragma unroll
+      for (int i = 0; i < WN; ++i) bp[i] = bp2[i];
     }
   };
 
@@ -1822,6 +1832,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     if (wg14 >= 200) return p.dh == 1 ? launch_sconv9<7, 1>(p, wg14, s) : launch_sconv9<7, 2>(p, wg14, s);
     if (wg8 >= 128) return p.dh == 1 ? launch_sconv9<4, 1>(p, wg8, s) : launch_sconv9<4, 2>(p, wg8, s);
   }
+  if (p.in2) p.ws = nullptr;   // two activation sources: the switch K-step is counted from K-step 0 (no split-K)
   if (p.pool_t2) {   // checked by the entry point: dense, bf16 out, even To; 128 x 128 tiles, no split-K
     p.ws = nullptr;
     return launch_cfg<4, 4>(p, batch, s, t.nst, 1);
@@ -2045,14 +2056,15 @@ extern "C" int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, i
 static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda, int ldb, int ldc, int batch,
                      long long strideA, long long strideB, long long strideC, float alpha, const float* bias,
                      long long strideBias, const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
-                     void* workspace, size_t workspace_bytes, trace_stream_t stream) {
+                     void* workspace, size_t workspace_bytes, trace_stream_t stream, const uint16_t* A2 = nullptr,
+                     int lda2 = 0, int K1 = 0) {
   TRACE_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   if (M == 0 || N == 0 || batch == 0) return 0;
   TRACE_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm: K, lda, ldb must be multiples of 8");
   TRACE_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "gemm: N and ldc must be multiples of 4");
   TRACE_REQUIRE(strideA % 8 == 0 && strideB % 8 == 0 && strideC % 4 == 0 && strideBias % 4 == 0,
                 "gemm: batch strides misaligned");
-  TRACE_REQUIRE(lda >= K && ldb >= K && ldc >= N, "gemm: leading dimensions too small");
+  TRACE_REQUIRE(lda >= (A2 ? K1 : K) && ldb >= K && ldc >= N, "gemm: leading dimensions too small");
   TRACE_REQUIRE(batch <= 65535, "gemm: batch too large");
   TRACE_REQUIRE(A && Bm && C, "gemm: null pointer");
   TRACE_REQUIRE(!(epilogue & (TRACE_EPI_RESIDUAL | TRACE_EPI_RES_POST)) || residual,
@@ -2089,6 +2101,14 @@ static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K,
   // split-K partials are dense [M][N]: only for the plain (non-batched) case
   p.ws = (batch == 1 && !((uintptr_t)workspace & 15)) ? workspace : nullptr;
   p.ws_bytes = workspace_bytes;
+  if (A2) {
+    TRACE_REQUIRE(batch == 1 && K1 > 0 && K1 < K && K1 % BK == 0 && (K - K1) % BK == 0 && lda2 >= K - K1 && lda2 % 8 == 0 &&
+                      ((uintptr_t)A2 & 15) == 0 && !p.w_tiled && !g_force_v2 && g_tune.tile != 10,
+                  "gemm: two-source form needs K1 and K - K1 multiples of 64, one batch, row-major weights");
+    p.in2 = A2;
+    p.pix2 = lda2;
+    p.k_switch = K1 / BK;
+  }
   return launch_igemm(p, batch, (hipStream_t)stream);
 }
 
@@ -2109,4 +2129,12 @@ extern "C" int trace_gemm_bf16_nt_ex(const uint16_t* A, const uint16_t* Bm, int 
                                      size_t workspace_bytes, trace_stream_t stream) {
   return gemm_impl(A, Bm, M, N, K, lda, ldb, ldc, batch, strideA, strideB, strideC, alpha, bias, strideBias, residual,
                    epilogue, C, C2, epilogue2, workspace, workspace_bytes, stream);
+}
+
+extern "C" int trace_gemm_bf16_nt_dual(const uint16_t* A, int lda, int K1, const uint16_t* A2, int lda2, int K2,
+                                       const uint16_t* Bm, int ldb, int M, int N, int ldc, const float* bias,
+                                       const void* residual, int epilogue, void* C, trace_stream_t stream) {
+  TRACE_REQUIRE(A2 && K1 > 0 && K2 > 0, "gemm_dual: bad shape");
+  return gemm_impl(A, Bm, M, N, K1 + K2, lda, ldb, ldc, 1, 0, 0, 0, 1.0f, bias, 0, residual, epilogue, C, nullptr, 0, nullptr, 0,
+                   stream, A2, lda2, K1);
 }

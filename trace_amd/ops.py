@@ -363,6 +363,25 @@ def tile_weights(w):
     return torch.gather(t, 3, src).contiguous().view(N, K)
 
 
+def gemm_nt_dual(A, A2, B, bias=None, relu=False):
+    """relu?([A | A2] @ B^T + bias): A (M,K1), A2 (M,K2) bf16 row-strided views, B (N, K1+K2) bf16; K1, K2 % 64 == 0.
+    One launch for relu(conv3(h) + downsample(x)) of a bottleneck with a stride-1 downsample."""
+    _, M, lda, _ = _rows(A, "A")
+    _, M2, lda2, _ = _rows(A2, "A2")
+    _, N, ldb, _ = _rows(B, "B")
+    K1, K2 = A.shape[-1], A2.shape[-1]
+    if A.dim() != 2 or A2.dim() != 2 or B.dim() != 2 or M2 != M or B.shape[1] != K1 + K2:
+        raise RuntimeError("gemm_nt_dual: shape mismatch")
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    nbytes = 2 * (M * (K1 + K2) + N * (K1 + K2) + M * N)
+    with torch.cuda.device(A.device), _span(2.0 * M * N * (K1 + K2), nbytes):
+        L.check(L.lib().trace_gemm_bf16_nt_dual(L.ptr(A), lda, K1, L.ptr(A2), lda2, K2, L.ptr(B), ldb, M, N, N, L.ptr(bias),
+                                                None, EPI_RELU if relu else 0, L.ptr(out), L.stream()), "gemm_bf16_nt_dual")
+    return out
+
+
 def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False, leaky=False,
             residual_post=False, out=None, out2=None, b_tiled=False):
     """C = alpha * A @ B^T (+bias)(+residual)(+ReLU | LeakyReLU(0.1))(+residual after the activation).

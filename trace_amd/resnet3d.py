@@ -187,6 +187,7 @@ class NonLocal3d(nn.Module):
 class Bottleneck3d(nn.Module):
     """resnet3d.py:155-318."""
     expansion = 4
+    fuse_downsample = True   # stride-1 downsample blocks: conv3 + downsample + add + ReLU as one two-source GEMM
 
     def __init__(self, inplanes, planes, spatial_stride=1, temporal_stride=1, dilation=1, downsample=None,
                  style='pytorch', inflate=True, inflate_style='3x1x1', non_local=False, non_local_cfg=dict(),
@@ -212,6 +213,7 @@ class Bottleneck3d(nn.Module):
                                 bias=False, norm_cfg=norm_cfg, act_cfg=act_cfg)
         self.conv3 = ConvModule(planes, planes * self.expansion, 1, bias=False, norm_cfg=norm_cfg, act_cfg=None)
         self.downsample = downsample
+        self._wcat = None
         self.non_local = non_local
         if non_local:
             self.non_local_block = NonLocal3d(planes * self.expansion, **non_local_cfg)
@@ -223,7 +225,20 @@ class Bottleneck3d(nn.Module):
 
     def run(self, x, pool_t2=False):
         """pool_t2: the MaxPool3d((2,1,1)) that follows this block (pool2 after layer1) rides in conv3's epilogue."""
-        identity = x if self.downsample is None else self.downsample.run(x)
+        ds = self.downsample
+        if (self.fuse_downsample and ds is not None and tuple(ds.conv.stride) == (1, 1, 1) and tuple(ds.conv.kernel_size) == (1, 1, 1)
+                and x.shape[-1] % 64 == 0 and self.conv3.conv.in_channels % 64 == 0 and not pool_t2):
+            # relu(conv3(h) + downsample(x)) as ONE GEMM over [h | x] with weights [W3 | Wd]: the downsample output is
+            # neither written nor re-read as the residual (layer1's and, with DC5, layer4's first block)
+            h = self.conv2.run(self.conv1.run(x))
+            if self._wcat is None or self._wcat[2] != _PACK_EPOCH[0]:
+                (w3, b3), (wd, bd) = self.conv3.packed(), ds.packed()
+                self._wcat = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous(), _PACK_EPOCH[0])
+            N_, T_, H_, W_, _ = h.shape
+            out = ops.gemm_nt_dual(h.view(-1, h.shape[-1]), x.view(-1, x.shape[-1]), self._wcat[0], bias=self._wcat[1],
+                                   relu=True).view(N_, T_, H_, W_, -1)
+            return self.non_local_block.run(out) if self.non_local else out
+        identity = x if ds is None else ds.run(x)
         out = self.conv2.run(self.conv1.run(x))
         fuse = pool_t2 and not self.non_local
         out = self.conv3.run(out, residual=identity, relu=True, pool_t2=fuse)  # resnet3d.py:306,313
