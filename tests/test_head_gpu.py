@@ -187,11 +187,14 @@ def test_overlapped_steps_equal_step_graph(setup):
         return [{k: o[k].clone() for k in keys} for o in outs]
 
     try:
+        # the overlapped tail stays on one stream and uses the fused pair kernel, so its numerics are those of the
+        # plain step graph without the second stream, whatever stream part A ran on
+        m.side_stream, m.graph_step, m.overlap_steps = False, True, False
+        m._step_graphs.clear()
+        want = [snap(run(case)) for case in seq]
         for side in (False, True):
-            m.side_stream, m.graph_step, m.overlap_steps = side, True, False
-            m._step_graphs.clear()
+            m.side_stream, m.graph_step = side, True
             m._ov_graphs.clear()
-            want = [snap(run(case)) for case in seq]
             m.overlap_steps = True
             got = []
             for case in seq:

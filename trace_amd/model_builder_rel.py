@@ -22,6 +22,7 @@ Small elementwise glue (softmax over 36 classes, LayerNorm(256), gathers, sigmoi
 the GPU; it is listed in DESIGN.md.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -914,7 +915,8 @@ class Generalized_RCNN(nn.Module):
                                                     ct3.temporal_r_feat_val, "treg")
             r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
             ev_r2c = None
-            if self.side_stream and self.fuse_pair_infer and self.split_pair_pool == "tail":
+            if (fork_b or os.environ.get("TRACE_TAIL_SPLIT")) and self.side_stream and self.fuse_pair_infer and \
+                    self.split_pair_pool == "tail":
                 # the union-box pooling of the pair kernel depends on nothing computed after part A: it runs on the
                 # second stream beside the object temporal branch, the tree-GRU (32 workgroups) and the query GEMMs -
                 # a chain of small launches that leaves most CUs idle - and only the combine stays on the critical path
