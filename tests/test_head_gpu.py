@@ -1,5 +1,6 @@
 """Relation head (ROIAlign -> heads -> temporal attention -> box tree / tree-GRU -> pair attention ->
-scoring): HIP path on B clips vs the fp32 oracle run clip by clip on the SAME temporal maps.
+scoring): HIP path on B clips vs the fp32 oracle run clip by clip on the SAME temporal maps (teacher-forced: the
+head in isolation; tests/test_e2e_gpu.py is the clip -> triplets comparison against the fp32 backbone).
 Tolerances (north_star): features rtol 2e-2 of the feature scale (bf16 vs fp32); relation
 triplets: top-100 >= 99 % identical."""
 import numpy as np
@@ -15,19 +16,20 @@ def rel(got, ref):
     return float((got - ref).norm() / (ref.norm() + 1e-12)), float((got - ref).abs().max() / (ref.abs().max() + 1e-12))
 
 
-def check_topk(want, got, full, strict=0.99):
-    """Top-k triplet agreement (north_star: >= 99 % identical).  Where fewer than `strict` agree, every
-    triplet the HIP path swapped in or out must be a near tie at a selection cut (the global top-k cut or a
-    pair's prd_k cut): its oracle score within 2 x 2e-2 (both sides of a cut carry the feature tolerance) of
-    the oracle score of a triplet it was swapped with, and at least 95 % must still be identical."""
+TOPK_LOG = []
+
+
+def check_topk(want, got, full=None, tag="", allow=None):
+    """Top-k triplet agreement, north_star: >= 99 % identical - at most ceil(k / 100) of the k triplets differ (1 of a
+    full top-100; a list shorter than 100 cannot express 99 % otherwise).  Prints the identity of every case."""
     same = len(want & got)
-    if same >= strict * len(want):
-        return
-    assert same >= 0.95 * len(want), (same, len(want))
-    out_, in_ = sorted(want - got), sorted(got - want)
-    for (pp, kk) in out_:
-        v = float(full[pp, kk])
-        assert any(abs(v - float(full[a, b])) <= 4e-2 * abs(v) for (a, b) in in_), (pp, kk, v)
+    k = max(len(want), 1)
+    ident = same / float(k)
+    TOPK_LOG.append((tag, ident))
+    print("top-%d identity %s: %.3f" % (len(want), tag, ident))
+    allow = -(-k // 100) if allow is None else allow
+    assert len(want) - same <= allow, (tag, same, len(want))
+    return ident
 
 
 def ref_sp(sd, ref):
@@ -219,8 +221,7 @@ def test_overlapped_steps_equal_step_graph(setup):
 
 def _check_head(m, sd, outs, blob, feat, rois, labels, scores, prd_k, dense_cut=False, **okw):
     """Shared checker: pair lists identical, logits rel-L2 < 2e-2, relation scores atol 2e-2, top-100 per
-    check_topk (with thousands of candidates and synthetic weights the scores around rank 100 are spaced
-    ~3e-7 apart, relative 3e-4, far below bf16 resolution: membership AT the cut is decided by rounding)."""
+    check_topk (>= 99 % identical, no second tolerance)."""
     from oracle.head_ref import head_forward
     from oracle.np_oracle import topk_triplets
     dbg = m._debug

@@ -188,19 +188,28 @@ def test_pair_infer_fused_vs_reference_order():
     assert torch.equal(sp3, sp2)
 
 
-@pytest.mark.parametrize("prd_k,topk", [(1, 100), (3, 100), (20, 50), (200, 7)])
-def test_rank_triplets_vs_oracle(prd_k, topk):
-    """task_evaluation_vg_and_vrd.py:207-228 per clip (ragged clips, one with fewer candidates than topk)."""
+@pytest.mark.parametrize("prd_k,topk,big", [(1, 100, 0), (3, 100, 0), (20, 50, 0), (200, 7, 0), (2, 100, 9900), (20, 100, 9900),
+                                            (132, 30, 2450)])
+def test_rank_triplets_vs_oracle(prd_k, topk, big):
+    """task_evaluation_vg_and_vrd.py:207-228 per clip (ragged clips, one with fewer candidates than topk).  `big`: one
+    clip with that many pairs - more than 16384 candidates, ranked in segments whose survivors are merged on chip
+    (configs[4]: 9 900 pairs; prd_k = 20 is the reference's VidVRD setting, :95); same list as one stable sort."""
     from trace_amd import ops
     from oracle import np_oracle
     rng = np.random.default_rng(prd_k)
     n_prd = 132
     pairs = [380, 2, 90, 0, 1, 600] if prd_k <= 20 else [120, 2, 90, 0, 1, 60]   # <= 16384 candidates per clip
+    if big:
+        pairs = [90, big, 0, 380]
     poff = np.concatenate([[0], np.cumsum(pairs)]).astype(np.int64)
     P = int(poff[-1])
     prd = rng.random((P, n_prd)).astype(np.float32)
     prd[5, :] = 0.5                                   # ties inside a pair: lowest predicate index first
     ss, os_ = rng.random(P).astype(np.float32), rng.random(P).astype(np.float32)
+    if big:                                           # ties across segments: equal top scores far apart in the candidate list
+        for q in (100, 90 + big - 3):
+            prd[q, :] = 0.999
+            ss[q] = os_[q] = 1.0
     sl, ol = rng.integers(1, 36, P), rng.integers(1, 36, P)
     t = lambda a: torch.from_numpy(a).to(DEV)
     out = ops.rank_triplets(t(prd), t(ss), t(os_), t(sl), t(ol), t(poff), max(pairs), topk, prd_k)
@@ -228,14 +237,17 @@ def test_rank_triplets_vs_oracle(prd_k, topk):
 
 
 def test_rank_triplets_rejects_oversize():
+    """More segments x topk than the on-chip merge holds: a clear error, no silent fallback."""
     from trace_amd import ops
-    P = 600
+    P = 20000
     z = torch.zeros((P,), device=DEV)
     lab = torch.ones((P,), dtype=torch.int64, device=DEV)
     poff = torch.tensor([0, P], dtype=torch.int64, device=DEV)
-    assert not ops.rank_triplets_supported(132, P, 132)
-    with pytest.raises(RuntimeError, match="candidates"):
-        ops.rank_triplets(torch.zeros((P, 132), device=DEV), z, z, lab, lab, poff, P, 10, 132)
+    assert ops.rank_triplets_supported(132, P, 132, 100)            # 162 segments x 100
+    assert not ops.rank_triplets_supported(132, P, 132, 200)
+    assert not ops.rank_triplets_supported(300, 10, 1, 10)          # predicate classes beyond the register budget
+    with pytest.raises(RuntimeError, match="segments"):
+        ops.rank_triplets(torch.zeros((P, 132), device=DEV), z, z, lab, lab, poff, P, 200, 132)
 
 
 @pytest.mark.parametrize("T,H,W,c", [(4, 28, 28, 256), (4, 14, 14, 512), (2, 6, 10, 64)])

@@ -154,8 +154,8 @@ def test_nms_ties_and_exact_threshold(golden):
     rng = np.random.default_rng(9)
     boxes = synth_boxes(rng, 200)
     scores = (rng.integers(0, 5, 200) / 5.0).astype(np.float32)
-    keep = _C.nms(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), 0.5)
-    assert np.array_equal(keep.cpu().numpy(), c_oracle.nms(boxes, scores, 0.5, 0))
+    keep = _C.nms(torch.from_numpy(boxes).to(DEV), torch.from_numpy(scores).to(DEV), 0.5)     # default = the CUDA rule (>)
+    assert np.array_equal(keep.cpu().numpy(), c_oracle.nms(boxes, scores, 0.5, 1))
 
 
 def test_nms_idempotent_full_size():

@@ -88,12 +88,19 @@ NMS_GE = 0  # Cython / CPU reference semantics (cython_nms.pyx:84, nms_cpu.cpp:6
 NMS_GT = 1  # CUDA reference semantics (cuda/nms.cu:60)
 
 
-def nms(dets, scores, threshold, mode=NMS_GE):
+NMS_MAX_BOXES = 16384  # one launch of trace_nms (csrc/nms.hip NMS_MAX_BOXES)
+
+
+def nms(dets, scores, threshold, mode=NMS_GT):
     """vision.cpp:8 / nms.h:10-28 — dets (N,4), scores (N,) -> int64 keep indices.
 
     Returns kept original indices in ascending order on the dets' device (empty
-    input -> empty CPU tensor as nms.h:17-18).  `mode` selects the reference's
-    CPU (>=, default: the path TRACE actually runs) or CUDA (>) comparison.
+    input -> empty CPU tensor as nms.h:17-18).  This binding only takes device
+    tensors, which the reference's `_C.nms` dispatches to nms_cuda: suppression on
+    IoU > thresh (cuda/nms.cu:60) - hence the default `mode`.  NMS_GE is the
+    Cython / CPU rule (>=, cython_nms.pyx:84, nms_cpu.cpp:60) that TRACE's run-time
+    NMS uses; `boxes.nms` / `boxes.nms_grouped` pass it explicitly.
+    More than NMS_MAX_BOXES boxes: see `boxes.nms_large`.
     """
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device="cpu")

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "../../include/trace_amd.h"
 
 namespace trace {
@@ -26,6 +28,31 @@ inline int check_launch(const char* what) {
       ::trace::set_error(__VA_ARGS__); \
       return 1;                       \
     }                                 \
+  } while (0)
+
+// More than 64 KiB of dynamic LDS must be opted into once per kernel AND per device (a function attribute belongs
+// to the current device's code object): `done` is the call site's per-device bitmap.
+inline int opt_in_lds(std::atomic<uint64_t>& done, const void* fn, int bytes, const char* what) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    set_error("%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(%d bytes of LDS): %s", what, bytes, hipGetErrorString(e));
+    return 1;
+  }
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return 0;
+}
+#define TRACE_LDS_OPT_IN(fn, bytes, what)                                                        \
+  do {                                                                                           \
+    static std::atomic<uint64_t> lds_done_{0};                                                   \
+    if (::trace::opt_in_lds(lds_done_, reinterpret_cast<const void*>(fn), (int)(bytes), what)) return 1; \
   } while (0)
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

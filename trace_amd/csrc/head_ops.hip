@@ -1013,6 +1013,99 @@ __global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __res
   }
 }
 
+// Two-level ranking for a clip with more than RANK_MAX_CAND candidates (configs[4]: 9 900 pairs x prd_k): workgroup
+// (s, b) sorts segment s (RANK_MAX_CAND candidates) of clip b and keeps its topk best as (score, clip-local candidate
+// index); rank_merge_topk_kernel then sorts the n_seg x topk survivors of a clip.  Both sort on (score descending,
+// candidate index ascending) - the total order of the single-pass kernel - so the result is the same list, ties included.
+__device__ __forceinline__ void rank_bitonic(float* key, int* idx, int npow2) {
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float si = key[i], sj = key[ixj];
+          const int ii = idx[i], ij = idx[ixj];
+          const bool up = ((i & k) == 0);
+          const bool swap = up ? rank_before(sj, ij, si, ii) : rank_before(si, ii, sj, ij);
+          if (swap) {
+            key[i] = sj;
+            key[ixj] = si;
+            idx[i] = ij;
+            idx[ixj] = ii;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void rank_seg_topk_kernel(const float* __restrict__ cand_score,
+                                                             const int64_t* __restrict__ poff, int kk, int topk,
+                                                             int n_seg, float* __restrict__ seg_score,
+                                                             int32_t* __restrict__ seg_idx) {
+  extern __shared__ __attribute__((aligned(16))) char rank_smem[];
+  float* key = (float*)rank_smem;
+  int* idx = (int*)(rank_smem + (size_t)RANK_MAX_CAND * sizeof(float));
+  const int b = blockIdx.y, sgm = blockIdx.x;
+  const long long p0 = poff[b], p1 = poff[b + 1];
+  const long long n = (p1 - p0) * kk;
+  const long long lo = (long long)sgm * RANK_MAX_CAND;
+  const int cnt = (int)(n - lo < 0 ? 0 : (n - lo > RANK_MAX_CAND ? RANK_MAX_CAND : n - lo));
+  const float* cs = cand_score + p0 * kk + lo;
+  for (int i = threadIdx.x; i < RANK_MAX_CAND; i += blockDim.x) {
+    key[i] = i < cnt ? cs[i] : -__builtin_inff();
+    idx[i] = i < cnt ? (int)(lo + i) : 0x7fffffff;
+  }
+  __syncthreads();
+  if (cnt > 0) rank_bitonic(key, idx, RANK_MAX_CAND);   // cnt is uniform over the workgroup
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    const long long o = ((long long)b * n_seg + sgm) * topk + j;
+    seg_score[o] = j < cnt ? key[j] : -__builtin_inff();
+    seg_idx[o] = j < cnt ? idx[j] : 0x7fffffff;
+  }
+}
+
+__global__ __launch_bounds__(1024) void rank_merge_topk_kernel(const float* __restrict__ seg_score,
+                                                               const int32_t* __restrict__ seg_idx, int n_in, int npow2,
+                                                               const int32_t* __restrict__ cand_prd,
+                                                               const int64_t* __restrict__ poff, int kk,
+                                                               const int64_t* __restrict__ sbj_lab,
+                                                               const int64_t* __restrict__ obj_lab, int topk,
+                                                               float* __restrict__ top_scores, int64_t* __restrict__ top_pair,
+                                                               int64_t* __restrict__ top_prd, int64_t* __restrict__ top_sbj,
+                                                               int64_t* __restrict__ top_obj) {
+  extern __shared__ __attribute__((aligned(16))) char rank_smem[];
+  float* key = (float*)rank_smem;
+  int* idx = (int*)(rank_smem + (size_t)npow2 * sizeof(float));
+  const int b = blockIdx.x;
+  const long long p0 = poff[b];
+  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+    key[i] = i < n_in ? seg_score[(long long)b * n_in + i] : -__builtin_inff();
+    idx[i] = i < n_in ? seg_idx[(long long)b * n_in + i] : 0x7fffffff;
+  }
+  __syncthreads();
+  rank_bitonic(key, idx, npow2);
+  for (int j = threadIdx.x; j < topk; j += blockDim.x) {
+    const long long o = (long long)b * topk + j;
+    const int c = idx[j];
+    if (c != 0x7fffffff) {
+      const long long pair = c / kk;
+      top_scores[o] = key[j];
+      top_pair[o] = pair;
+      top_prd[o] = cand_prd[p0 * kk + c];
+      top_sbj[o] = sbj_lab[p0 + pair];
+      top_obj[o] = obj_lab[p0 + pair];
+    } else {
+      top_scores[o] = -1.0f;
+      top_pair[o] = 0;
+      top_prd[o] = 0;
+      top_sbj[o] = 0;
+      top_obj[o] = 0;
+    }
+  }
+}
+
 }  // namespace trace
 
 using namespace trace;
@@ -1146,16 +1239,8 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
     const size_t need = ((size_t)3 * FH * Hd + (size_t)max_tree_nodes * (6 * Hd + (F > Hd ? F - Hd : 0)) + 4 * Hd + 3 * (size_t)max_tree_nodes + 4) *
                         sizeof(float);  // xt(3) + h + hd + ws|x, biases, topology
     if (need <= 156 * 1024) {
-      static bool attr2 = false;
-      if (!attr2) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel<0, 0>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_lds_kernel<64, 64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr2 = true;
-      }
+      TRACE_LDS_OPT_IN((&tree_gru_lds_kernel<0, 0>), 156 * 1024, "tree_gru");
+      TRACE_LDS_OPT_IN((&tree_gru_lds_kernel<64, 64>), 156 * 1024, "tree_gru");
       // the pass is a chain of ~4 x levels barrier-separated phases of (nodes of a level) x Hd outputs: more waves per
       // workgroup = fewer rounds per phase (TRACE_TREE_THREADS: A/B measurements)
       static const int tree_threads = [] {
@@ -1174,13 +1259,7 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
   }
   const size_t lds = (size_t)(3 * F * Hd + 3 * Hd * Hd) * sizeof(float);
   if (lds <= 128 * 1024) {
-    static bool attr_set = false;  // raise the dynamic-LDS limit once (idempotent)
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tree_gru_kernel<true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      TRACE_REQUIRE(e == hipSuccess, "tree_gru: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_set = true;
-    }
+    TRACE_LDS_OPT_IN(&tree_gru_kernel<true>, 128 * 1024, "tree_gru");
     hipLaunchKernelGGL(tree_gru_kernel<true>, dim3(n_trees, n_groups), dim3(256), lds, (hipStream_t)stream, p);
   } else {
     hipLaunchKernelGGL(tree_gru_kernel<false>, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
@@ -1193,6 +1272,20 @@ extern "C" size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k) {
   return (size_t)P_total * prd_k * 8 + 256;
 }
 
+static int rank_segments(int max_pairs_per_clip, int kk) {
+  const long long cand = (long long)max_pairs_per_clip * kk;
+  return cand <= RANK_MAX_CAND ? 1 : (int)((cand + RANK_MAX_CAND - 1) / RANK_MAX_CAND);
+}
+
+extern "C" size_t trace_rank_triplets_workspace_bytes_ex(int P_total, int prd_k, int n_clips, int max_pairs_per_clip,
+                                                         int topk) {
+  if (P_total < 0 || prd_k < 0 || n_clips < 0 || max_pairs_per_clip < 0 || topk < 0) return 0;
+  size_t base = (((size_t)P_total * prd_k * 4 + 255) & ~(size_t)255) * 2 + 256;
+  const int n_seg = rank_segments(max_pairs_per_clip, prd_k);
+  if (n_seg > 1) base += (((size_t)n_clips * n_seg * topk * 4 + 255) & ~(size_t)255) * 2;
+  return base;
+}
+
 extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, int ld_prd, const float* sbj_scores,
                                    const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
                                    const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,
@@ -1203,32 +1296,47 @@ extern "C" int trace_rank_triplets(const float* prd, int P_total, int n_prd, int
                 "rank_triplets: bad shape");
   TRACE_REQUIRE(n_prd <= RANK_MAX_PRD, "rank_triplets: %d predicate classes exceed the supported %d", n_prd, RANK_MAX_PRD);
   const int kk = prd_k < n_prd ? prd_k : n_prd;
-  TRACE_REQUIRE((long long)max_pairs_per_clip * kk <= RANK_MAX_CAND,
-                "rank_triplets: %d pairs x %d predicates per clip exceed the %d candidates sorted on chip",
-                max_pairs_per_clip, kk, RANK_MAX_CAND);
+  const int n_seg = rank_segments(max_pairs_per_clip, kk);
+  TRACE_REQUIRE((long long)n_seg * topk <= RANK_MAX_CAND,
+                "rank_triplets: %d pairs x %d predicates per clip need %d segments x topk %d > the %d survivors merged on chip",
+                max_pairs_per_clip, kk, n_seg, topk, RANK_MAX_CAND);
   if (n_clips == 0) return 0;
   TRACE_REQUIRE(pair_off && top_scores && top_pair && top_prd && top_sbj && top_obj, "rank_triplets: null pointer");
   TRACE_REQUIRE(P_total == 0 || (prd && sbj_scores && obj_scores && sbj_labels && obj_labels && workspace),
                 "rank_triplets: null pointer");
-  TRACE_REQUIRE(workspace_bytes >= trace_rank_triplets_workspace_bytes(P_total, kk), "rank_triplets: workspace too small");
+  const size_t need = n_seg > 1 ? trace_rank_triplets_workspace_bytes_ex(P_total, kk, n_clips, max_pairs_per_clip, topk)
+                                : trace_rank_triplets_workspace_bytes(P_total, kk);
+  TRACE_REQUIRE(workspace_bytes >= need, "rank_triplets: workspace too small (%zu < %zu)", workspace_bytes, need);
   TRACE_REQUIRE(((uintptr_t)workspace & 255) == 0, "rank_triplets: workspace must be 256-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  const size_t cand_bytes = ((size_t)P_total * kk * 4 + 255) & ~(size_t)255;
   float* cand_score = (float*)workspace;
-  int32_t* cand_prd = (int32_t*)((char*)workspace + (((size_t)P_total * kk * 4 + 255) & ~(size_t)255));
+  int32_t* cand_prd = (int32_t*)((char*)workspace + cand_bytes);
   if (P_total > 0)
     hipLaunchKernelGGL(rank_pair_topk_kernel, dim3(ceil_div(P_total, 4)), dim3(256), 0, s, prd, n_prd, ld_prd, sbj_scores,
                        obj_scores, P_total, kk, cand_score, cand_prd);
+  if (n_seg > 1) {
+    const size_t seg_bytes = ((size_t)n_clips * n_seg * topk * 4 + 255) & ~(size_t)255;
+    float* seg_score = (float*)((char*)workspace + 2 * cand_bytes);
+    int32_t* seg_idx = (int32_t*)((char*)workspace + 2 * cand_bytes + seg_bytes);
+    TRACE_LDS_OPT_IN(&rank_seg_topk_kernel, RANK_MAX_CAND * 8, "rank_triplets");
+    hipLaunchKernelGGL(rank_seg_topk_kernel, dim3(n_seg, n_clips), dim3(1024), (size_t)RANK_MAX_CAND * 8, s, cand_score,
+                       pair_off, kk, topk, n_seg, seg_score, seg_idx);
+    const int n_in = n_seg * topk;
+    int np2 = 64;
+    while (np2 < n_in) np2 <<= 1;
+    if ((size_t)np2 * 8 > 64 * 1024) {
+      TRACE_LDS_OPT_IN(&rank_merge_topk_kernel, RANK_MAX_CAND * 8, "rank_triplets");
+    }
+    hipLaunchKernelGGL(rank_merge_topk_kernel, dim3(n_clips), dim3(1024), (size_t)np2 * 8, s, seg_score, seg_idx, n_in, np2,
+                       cand_prd, pair_off, kk, sbj_labels, obj_labels, topk, top_scores, top_pair, top_prd, top_sbj, top_obj);
+    return check_launch("rank_triplets(segmented)");
+  }
   int npow2 = 64;
   while (npow2 < max_pairs_per_clip * kk) npow2 <<= 1;
   const size_t lds = (size_t)npow2 * 8;
   if (lds > 64 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_clip_topk_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, RANK_MAX_CAND * 8);
-      TRACE_REQUIRE(e == hipSuccess, "rank_triplets: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr = true;
-    }
+    TRACE_LDS_OPT_IN(&rank_clip_topk_kernel, RANK_MAX_CAND * 8, "rank_triplets");
   }
   hipLaunchKernelGGL(rank_clip_topk_kernel, dim3(n_clips), dim3(1024), lds, s, cand_score, cand_prd, pair_off, kk,
                      sbj_labels, obj_labels, topk, npow2, top_scores, top_pair, top_prd, top_sbj, top_obj);

@@ -1238,12 +1238,7 @@ static int launch_wsgemm(IgemmParams& p, hipStream_t s, int ksplit_req) {
   p.ksplit = ceil_div(ksteps, p.ks_per);
   p.partial = (float*)p.ws;
   constexpr int LDS = 3 * 16 * WN * 128;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wsgemm_bf16_kernel<WN>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  TRACE_LDS_OPT_IN((&wsgemm_bf16_kernel<WN>), LDS, "igemm");
   hipLaunchKernelGGL((wsgemm_bf16_kernel<WN>), dim3(tiles_n, p.ksplit), dim3(256), LDS, s, p);
   // the reduce kernel sums `ksplit` slabs (one included) and applies the epilogue
   long long n4 = (long long)p.M * (p.Cout >> 2);
@@ -1409,12 +1404,7 @@ static int launch_tconv3(IgemmParams& p, int N, hipStream_t s) {
     set_error("conv3d: grid too large");
     return 1;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tconv3_bf16_kernel<WM, LOGQ>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    attr_done = true;
-  }
+  TRACE_LDS_OPT_IN((&tconv3_bf16_kernel<WM, LOGQ>), LDS, "igemm");
   hipLaunchKernelGGL((tconv3_bf16_kernel<WM, LOGQ>), dim3((unsigned)nwg), dim3(256), LDS, s, p);
   return check_launch("conv3d_tconv3");
 }
@@ -1649,12 +1639,7 @@ static int launch_sconv9_kg(IgemmParams& p, long long nwg, hipStream_t s) {
   p.tiles_n = ceil_div(p.Cout, 64);
   p.ksplit = 1;
   p.ks_per = 0;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sconv9_bf16_kernel<WN, D, KG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    attr_done = true;
-  }
+  TRACE_LDS_OPT_IN((&sconv9_bf16_kernel<WN, D, KG>), LDS_MAX, "igemm");
   const int lds = (p.Crun > BK ? 2 : 1) * PATCH_BYTES + SC_NA * 64 * 128;   // one 64-channel chunk: no second patch stage
   hipLaunchKernelGGL((sconv9_bf16_kernel<WN, D, KG>), dim3((unsigned)nwg), dim3(256 * KG), lds, s, p);
   return check_launch("conv3d_sconv9");
@@ -1755,22 +1740,12 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
   {
 #define TRACE_IGEMM2(D, S)                                                                               \
   do {                                                                                                   \
-    static bool attr_done = false; /* > 64 KiB of dynamic LDS must be opted into once per kernel */      \
-    if (!attr_done) {                                                                                    \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_bf16_kernel<WM, WN, D, S>),        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * stage));           \
-      attr_done = true;                                                                                  \
-    }                                                                                                    \
+    TRACE_LDS_OPT_IN((&igemm2_bf16_kernel<WM, WN, D, S>), S * stage, "igemm"); \
     hipLaunchKernelGGL((igemm2_bf16_kernel<WM, WN, D, S>), grid, dim3(256), S * stage, s, p);           \
   } while (0)
 #define TRACE_IGEMM3(D, S)                                                                               \
   do {                                                                                                   \
-    static bool attr_done3 = false;                                                                      \
-    if (!attr_done3) {                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm3_bf16_kernel<WM, WN, D, S>),        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(S * stage));           \
-      attr_done3 = true;                                                                                 \
-    }                                                                                                    \
+    TRACE_LDS_OPT_IN((&igemm3_bf16_kernel<WM, WN, D, S>), S * stage, "igemm"); \
     hipLaunchKernelGGL((igemm3_bf16_kernel<WM, WN, D, S>), grid, dim3(256), lds_stages * stage, s, p);  \
   } while (0)
     // v3 main loop (eligibility computed above): a K-step must not straddle a tap, taps must fit the 32-bit
@@ -1994,12 +1969,7 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
   if (kt == ST_KT && kh == ST_KH && kwp == 8 && Cp == 4 && Cout == 64 && sh == 2 && sw == 2 && Ho % 16 == 0 &&
       Wo % 16 == 0 && !(epilogue & TRACE_EPI_OUT_F32) && !g_force_v2 && g_tune.tile == 0) {
     // TRACE's stem shape: LDS-resident input patch (stem16_bf16_kernel); anything else takes the generic loop
-    static bool attr_done = false;
-    if (!attr_done) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-      attr_done = true;
-    }
+    TRACE_LDS_OPT_IN((&stem16_bf16_kernel<false>), ST_LDS, "igemm");
     const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
     TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem: grid too large");
     hipLaunchKernelGGL(stem16_bf16_kernel<false>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
@@ -2041,12 +2011,7 @@ extern "C" int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, i
   p.ldo = 64;
   p.alpha = 1.0f;
   p.epi = epilogue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stem16_bf16_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS);
-    attr_done = true;
-  }
+  TRACE_LDS_OPT_IN((&stem16_bf16_kernel<true>), ST_LDS, "igemm");
   const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
   TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem16_f32: grid too large");
   hipLaunchKernelGGL(stem16_bf16_kernel<true>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);

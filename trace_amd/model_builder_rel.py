@@ -209,6 +209,16 @@ class Generalized_RCNN(nn.Module):
         # branch, tree-GRU, query GEMMs); True: beside the backbone (measured no faster than the fused launch: 2.869 vs
         # 2.852 ms/step); False: one fused launch after the tree-GRU
         self.split_pair_pool = "tail"
+        # a checkpoint loaded into a SUB-module (model.Box_Head.load_state_dict(..)) never reaches this class's
+        # load_state_dict: every sub-module drops the packed weights (and the captured graphs, through the epoch in
+        # their keys) from a post-hook of its own load
+        for mod in self.modules():
+            if mod is not self:
+                mod.register_load_state_dict_post_hook(self._on_submodule_load)
+
+    def _on_submodule_load(self, module, incompatible_keys):
+        self._pk = {}
+        self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
 
     # ------------------------------------------------------------------ packed-weight cache
     def _apply(self, fn, *a, **k):
@@ -391,7 +401,8 @@ class Generalized_RCNN(nn.Module):
         returned tensors are the graph's output buffers: they are overwritten by the next replay."""
         dev = all_frames.device
         key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
-               feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch)
+               feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
+               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
         depth = max(1, int(self.pipeline))
         ents = self._step_graphs.get(key)
         if ents is None:
@@ -478,7 +489,7 @@ class Generalized_RCNN(nn.Module):
         dev = all_frames.device
         key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
-               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs)
+               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
         flushed = None
         if self._ov_pending is not None and self._ov_pending["key"] != key:
             flushed = self.flush_steps()          # another step signature: no graph holds that pair of steps
@@ -996,12 +1007,11 @@ class Generalized_RCNN(nn.Module):
         top = None
         if topk:
             pmax = int(np.max(np.diff(poff))) if len(poff) > 1 else 0
-            if ops.rank_triplets_supported(prd.shape[1], pmax, prd_k):
-                top = ops.rank_triplets(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all, dv[ix["poff"]], pmax,
-                                        min(topk, max(pmax * min(prd_k, prd.shape[1]), 1)), prd_k)
-            else:   # more candidates per clip than the on-chip sort holds: torch's top-k on the GPU
-                top = self.topk_triplets_batched(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all,
-                                                 dv[ix["pclip"]], poff, dv[ix["poff"]][:-1], topk, prd_k)
+            k_out = min(topk, max(pmax * min(prd_k, prd.shape[1]), 1))
+            if not ops.rank_triplets_supported(prd.shape[1], pmax, prd_k, k_out):
+                raise RuntimeError("rank_triplets: %d predicate classes / %d pairs x prd_k %d / topk %d exceed the device "
+                                   "ranking's limits (see trace_rank_triplets)" % (prd.shape[1], pmax, prd_k, k_out))
+            top = ops.rank_triplets(prd, sbj_sc_all, obj_sc_all, sbj_lab_all, obj_lab_all, dv[ix["poff"]], pmax, k_out, prd_k)
         self._debug = dict(det_feat=det_feat, obj_agg=obj_agg, reg_agg=reg_agg, pf=pf, obj_feature=obj_feature,
                            q_s=q_s, q_o=q_o, s_map=s_map, o_map=o_map, v_map=v_map, sp=sp.view(P, ps * ps, low),
                            spatio_infer=spatio_infer,

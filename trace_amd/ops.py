@@ -660,8 +660,12 @@ RANK_MAX_PRD = 256
 RANK_MAX_CAND = 16384
 
 
-def rank_triplets_supported(n_prd, max_pairs_per_clip, prd_k):
-    return n_prd <= RANK_MAX_PRD and max_pairs_per_clip * min(prd_k, n_prd) <= RANK_MAX_CAND
+def rank_triplets_supported(n_prd, max_pairs_per_clip, prd_k, topk=100):
+    """One on-chip sort per clip up to RANK_MAX_CAND candidates; above that segments of RANK_MAX_CAND whose topk
+    survivors are merged on chip (segments x topk <= RANK_MAX_CAND)."""
+    cand = max_pairs_per_clip * min(prd_k, n_prd)
+    n_seg = max(1, -(-cand // RANK_MAX_CAND))
+    return n_prd <= RANK_MAX_PRD and (n_seg == 1 or n_seg * topk <= RANK_MAX_CAND)
 
 
 def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off, max_pairs_per_clip, topk, prd_k=1):
@@ -679,7 +683,7 @@ def rank_triplets(prd, sbj_scores, obj_scores, sbj_labels, obj_labels, pair_off,
     dev = prd.device
     kk = min(prd_k, n_prd)
     lib = L.lib()
-    ws_bytes = lib.trace_rank_triplets_workspace_bytes(P, kk)
+    ws_bytes = lib.trace_rank_triplets_workspace_bytes_ex(P, kk, B, int(max_pairs_per_clip), int(topk))
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     top = torch.empty((B, topk), dtype=torch.float32, device=dev)
     outs = [torch.empty((B, topk), dtype=torch.int64, device=dev) for _ in range(4)]

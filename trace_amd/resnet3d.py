@@ -48,6 +48,8 @@ class ConvModule(nn.Module):
 
     def packed(self):
         """(w (Cout, taps*Cin) bf16 with BN scale folded, bias (Cout) f32)."""
+        if self._packed is not None and self._packed[2] != _PACK_EPOCH[0]:
+            self._packed = None       # BN buffers / weights were reloaded somewhere in the tree since this was folded
         if self._packed is None:
             w = self.conv.weight.detach().float()
             cout = w.shape[0]
@@ -61,8 +63,8 @@ class ConvModule(nn.Module):
                 shift = shift + self.conv.bias.detach().float() * scale
             w = w * scale.view(-1, 1, 1, 1, 1)
             wp = w.permute(0, 2, 3, 4, 1).reshape(cout, -1).contiguous().to(torch.bfloat16)
-            self._packed = (wp, shift.contiguous())
-        return self._packed
+            self._packed = (wp, shift.contiguous(), _PACK_EPOCH[0])
+        return self._packed[:2]
 
     def forward(self, x):
         """Plain torch path (NCTHW f32, autograd-capable): used for training-side work and for
@@ -333,6 +335,10 @@ class ResNet3d(nn.Module):
     stem_from_f32 = True   # TRACE's stem shape reads the f32 clip directly (ops.conv3d_stem_f32); False: padded bf16 copy first
 
     def _stem_weights(self):
+        # keyed by the pack epoch like Bottleneck3d._wcat / NonLocal3d._tpg: a parent module's load_state_dict reaches
+        # conv1 through _load_from_state_dict (which bumps the epoch) without ever calling ResNet3d.load_state_dict
+        if self._stem_packed is not None and self._stem_packed[3] != _PACK_EPOCH[0]:
+            self._stem_packed = None
         if self._stem_packed is None:
             kt, kh, kw = self.conv1_kernel
             kwp = (kw + 1) // 2 * 2  # even number of pixels: kwp*CP % 8 == 0
@@ -343,8 +349,9 @@ class ResNet3d(nn.Module):
             w = w * scale.view(-1, 1, 1, 1, 1)
             wp = torch.zeros((w.shape[0], kt, kh, kwp, self.CP), device=w.device)
             wp[:, :, :, :kw, :w.shape[1]] = w.permute(0, 2, 3, 4, 1)
-            self._stem_packed = (wp.reshape(w.shape[0], -1).to(torch.bfloat16).contiguous(), b.contiguous(), kwp)
-        return self._stem_packed
+            self._stem_packed = (wp.reshape(w.shape[0], -1).to(torch.bfloat16).contiguous(), b.contiguous(), kwp,
+                                 _PACK_EPOCH[0])
+        return self._stem_packed[:3]
 
     def _run_stem(self, x, in_ntchw):
         """conv1 + BN + ReLU + maxpool (resnet3d.py:795-796).  The pool's kernel_t is 1 with
