@@ -113,6 +113,15 @@ int trace_nms_grouped(const float* boxes, const float* scores, const int32_t* gr
                       int32_t* num_keep, void* workspace, size_t workspace_bytes,
                       trace_stream_t stream);
 
+/* trace_nms for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc): NO counterpart in the reference.  Same result as trace_nms, but the scratch is a
+ * 2.13 MiB array inside the library's device image (one copy per GPU, kept until the process ends) instead of
+ * a caller workspace; calls no hipMalloc / hipFree or other allocating routine.  N <= 4096 boxes (error
+ * otherwise).  All calls on one GPU share that array: calls that overlap on one GPU (two streams, two
+ * threads) race - order them on one stream. */
+int trace_nms_noalloc(const float* boxes, const float* scores, int N, float thresh, int mode,
+                      int64_t* keep_out, int32_t* num_keep, trace_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* Box helpers                                                               */
 /* ------------------------------------------------------------------------ */
@@ -419,9 +428,14 @@ int trace_pair_assemble(const int64_t* det_labels, const float* det_scores, cons
  * Per pair the prd_k best predicates, score = sbj*obj*prd, per clip the topk best cells in descending score
  * (ties: ascending (pair, slot) index = a stable descending sort).  ld_prd = row stride of prd (>= n_prd).  Outputs (n_clips, topk): scores f32,
  * clip-local pair index, predicate index, subject / object label (int64); rows of a clip with fewer than
- * topk candidates are padded with score -1.  Limits: n_prd <= 256, max_pairs_per_clip*min(prd_k,n_prd) <= 16384
- * (error otherwise).  workspace: trace_rank_triplets_workspace_bytes(P_total, min(prd_k,n_prd)) bytes, 256-aligned. */
+ * topk candidates are padded with score -1.  A clip with up to 16384 candidates (pairs x min(prd_k,n_prd)) is sorted
+ * in one pass on chip; a larger one (configs "100 objects, ~10k pairs") in segments of 16384 whose topk survivors are
+ * merged by a second on-chip sort on the same (score, candidate index) order - the same list, ties included.
+ * Limits: n_prd <= 256, segments x topk <= 16384 (error otherwise).
+ * workspace, 256-aligned: trace_rank_triplets_workspace_bytes(P_total, min(prd_k,n_prd)) bytes for the one-pass case,
+ * trace_rank_triplets_workspace_bytes_ex(...) for either case. */
 size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k);
+size_t trace_rank_triplets_workspace_bytes_ex(int P_total, int prd_k, int n_clips, int max_pairs_per_clip, int topk);
 int trace_rank_triplets(const float* prd, int P_total, int n_prd, int ld_prd, const float* sbj_scores,
                         const float* obj_scores, const int64_t* sbj_labels, const int64_t* obj_labels,
                         const int64_t* pair_off, int n_clips, int max_pairs_per_clip, int prd_k, int topk,

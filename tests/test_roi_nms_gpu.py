@@ -121,12 +121,15 @@ def test_roi_align_full_size_constant_property():
 
 
 def test_nms_golden_bitexact(golden):
+    """Golden keeps come from the reference's own CPU kernel (nms_cpu.cpp, `>=`): NMS_GE.  The default mode of the
+    device binding is the CUDA rule (`>`), see test_nms_ties_and_exact_threshold."""
+    from trace_amd import _C
     from trace_amd.roi_layers import nms
     g = golden("nms.npz")
     names = sorted({k.rsplit("_", 1)[0] for k in g.files})
     for n in names:
         keep = nms(torch.from_numpy(g[n + "_boxes"]).to(DEV), torch.from_numpy(g[n + "_scores"]).to(DEV),
-                   float(g[n + "_thresh"]))
+                   float(g[n + "_thresh"]), _C.NMS_GE)
         assert keep.dtype == torch.int64
         assert np.array_equal(keep.cpu().numpy(), g[n + "_keep"]), n
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "trace_nl_pool_split_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "trace_nl_pool_split2_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
     "trace_rank_triplets_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "trace_rank_triplets_workspace_bytes_ex": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "trace_rank_triplets": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_size_t, P]),
     "trace_act_cast_bf16": (c_int, [P, c_int, P, c_int, c_longlong, c_int, P, P]),
     "trace_layernorm_act_bf16": (c_int, [P, c_int, c_int, P, P, c_float, c_int, P, P]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
     "trace_nms_grouped": (c_int, [P, P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),
+    "trace_nms_noalloc": (c_int, [P, P, c_int, c_float, c_int, P, P, P]),
     "trace_bbox_transform_clip": (c_int, [P, P, c_int, c_int] + [c_float] * 7 + [P, P]),
     "trace_fpn_levels": (c_int, [P, c_int, c_int, c_int, c_float, c_float, P, P]),
     "trace_bbox_overlaps": (c_int, [P, c_int, P, c_int, P, P]),

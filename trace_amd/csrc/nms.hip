@@ -15,11 +15,20 @@
 //
 // Compiled with -ffp-contract=off: IoU is the reference's f32 expression, bit
 // for bit.
+#include <mutex>
+
 #include "common.h"
 
 namespace trace {
 
 constexpr int NMS_MAX_BOXES = 16384;  // 128 KiB of LDS for the sort; 256 mask words per row (4 per lane)
+
+// trace_nms_noalloc: its scratch lives in the library's own device image (one copy per GPU, held until the process
+// ends) instead of a caller workspace.  Layout = carve(NMS_STATIC_MAX_BOXES): order 16 KiB + sorted boxes 64 KiB +
+// areas 16 KiB + suppression mask 4096 x 64 words = 2 MiB + keep flags 16 KiB + groups 16 KiB.
+constexpr int NMS_STATIC_MAX_BOXES = 4096;
+constexpr size_t NMS_STATIC_BYTES = 16384 + 65536 + 16384 + (size_t)4096 * 64 * 8 + 16384 + 16384;
+static __device__ __align__(256) unsigned char scratch[NMS_STATIC_BYTES];
 
 struct NmsWorkspace {
   int32_t* order;   // [Npad64] sorted -> original index
@@ -275,13 +284,7 @@ static int nms_launch(const float* boxes, const float* scores, const int32_t* gr
   while (npow2 < N) npow2 <<= 1;
   size_t lds = (size_t)npow2 * 8;
   if (lds > 64 * 1024) {
-    static bool attr = false;  // > 64 KiB of dynamic LDS must be opted into once
-    if (!attr) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_sort_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, NMS_MAX_BOXES * 8);
-      TRACE_REQUIRE(e == hipSuccess, "nms: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr = true;
-    }
+    TRACE_LDS_OPT_IN(&nms_sort_kernel, NMS_MAX_BOXES * 8, "nms");
   }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, N, npow2, npad,
                      ws.order, ws.sboxes, ws.sareas, group, ws.sgroup);
@@ -306,4 +309,44 @@ extern "C" int trace_nms_grouped(const float* boxes, const float* scores, const 
   TRACE_REQUIRE(N == 0 || group, "nms_grouped: null group array");
   return nms_launch(boxes, scores, group, N, thresh, mode, keep_out, num_keep, workspace, workspace_bytes,
                     stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing (see include/trace_amd.h).  `scratch` above is a host-side stand-in
+// in host code, not a device address: the address of each GPU's own copy comes from hipGetSymbolAddress, once
+// per device with that device current, and only that pointer is ever handed to a kernel.
+// ---------------------------------------------------------------------------------------------------------
+namespace trace {
+constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_of_current_device(void** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  TRACE_REQUIRE(e == hipSuccess, "nms_noalloc: hipGetDevice: %s", hipGetErrorString(e));
+  TRACE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "nms_noalloc: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    TRACE_REQUIRE(e == hipSuccess && p, "nms_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace trace
+
+extern "C" int trace_nms_noalloc(const float* boxes, const float* scores, int N, float thresh, int mode,
+                                 int64_t* keep_out, int32_t* num_keep, trace_stream_t stream) {
+  TRACE_REQUIRE(N <= NMS_STATIC_MAX_BOXES, "nms_noalloc: %d boxes exceeds the built-in scratch (max %d boxes); use "
+                "trace_nms with a caller workspace", N, NMS_STATIC_MAX_BOXES);
+  static_assert(NMS_STATIC_MAX_BOXES % 64 == 0, "scratch layout assumes whole 64-box blocks");
+  void* ws = nullptr;
+  if (scratch_of_current_device(&ws)) return 1;
+  TRACE_REQUIRE(carve(NMS_STATIC_MAX_BOXES, nullptr, nullptr) <= NMS_STATIC_BYTES, "nms_noalloc: scratch layout outgrew its array");
+  // every word the kernels read (sorted arrays, upper-triangle mask words, keep flags) is written by this call
+  // first, so nothing of the previous call's contents has to be cleared
+  return nms_launch(boxes, scores, nullptr, N, thresh, mode, keep_out, num_keep, ws, NMS_STATIC_BYTES, stream);
 }
