@@ -419,6 +419,16 @@ int trace_pair_assemble(const int64_t* det_labels, const float* det_scores, cons
                         const float* part_s, const float* part_o, int wp, const float* freq, int n_rel,
                         int n_obj, int64_t* sbj_lab, int64_t* obj_lab, float* sbj_sc, float* obj_sc,
                         float* so_bias, float* so_part, trace_stream_t stream);
+/* Same with optional per-pair labels / scores (each NULL or P entries): pair_sbj_lab / pair_obj_lab replace
+ * det_labels[X] / det_labels[Y] (outputs and frequency-bias row), pair_sbj_sc / pair_obj_sc replace det_scores[X] /
+ * det_scores[Y] - the `use_gt_labels` path of the gt-box branch (model_builder_rel.py:844-858, 871-876, 1051-1064),
+ * where the labels come with the annotated pairs rather than with the de-duplicated boxes. */
+int trace_pair_assemble_ex(const int64_t* det_labels, const float* det_scores, const int64_t* X, const int64_t* Y,
+                           int P, const int64_t* pair_sbj_lab, const int64_t* pair_obj_lab, const float* pair_sbj_sc,
+                           const float* pair_obj_sc, const float* low_s, const float* low_o, int wl, const float* part_s,
+                           const float* part_o, int wp, const float* freq, int n_rel, int n_obj, int64_t* sbj_lab,
+                           int64_t* obj_lab, float* sbj_sc, float* obj_sc, float* so_bias, float* so_part,
+                           trace_stream_t stream);
 
 /* Top-k triplet ranking - lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 (+ argsort_desc,
  * lib/datasets_rel/pytorch_misc.py:28-35), for every clip of a step at once, so that only topk records per

@@ -186,12 +186,17 @@ def sem_feat(sd, softmax_obj_vec, region_feature, lca, sbj_inds, obj_inds):
 
 def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale=1.0, groups=4,
                  low_dim=256, max_tree_height=7, partition=2, conv_scale=1.0 / 16, rel_scale=1.0 / 16,
-                 det_labels_in=None, det_scores_in=None, dataset_name="vidvrd", use_ovlp_filter=False):
+                 det_labels_in=None, det_scores_in=None, dataset_name="vidvrd", use_ovlp_filter=False,
+                 pairs=None, pair_labels=None):
     """One clip.
       blob_conv (1,2048,H,W)  Conv_Body output (model_builder_rel.py:702)
       feat_map  (1,2048,h,w)  Prd_RCNN2D output (:1006-1007)
       tmaps     (T',2048,h,w) I3D output frames (:978-981)
       det_rois  (n,5) f32 [0,x1,y1,x2,y2] in the scaled key-frame (:894)
+      pairs = (sbj_inds, obj_inds): the gt-box branch (:772-888), where det_rois are the de-duplicated gt boxes and
+              the pairs are the annotated ones (np_oracle.gt_box_pairs); Box_Head / S_Head / O_Head pool sbj_rois /
+              obj_rois there (:824-829, :887-888), which are det_rois[sbj_inds] / det_rois[obj_inds] row for row
+      pair_labels = dict(sbj_labels, obj_labels [1-based], sbj_scores, obj_scores) per pair: use_gt_labels (:844-858)
     Returns dict with prd_scores (P,n_prd), obj_scores (n,C), det_labels, det_scores, sbj_inds,
     obj_inds, lca and intermediate features."""
     sd = {k: v.float().cpu() for k, v in sd.items()}
@@ -207,9 +212,13 @@ def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale
     if det_labels_in is not None:                                         # `prd_category` records (:895-898) /
         det_labels = np.asarray(det_labels_in).astype(np.int32)           # prepare_det_rois output (:912-915)
         det_scores = np.asarray(det_scores_in).astype(np.float32)
-    sbj_inds, obj_inds, rel_rois = np_oracle.relpn_pairs(det_rois, det_labels if det_labels_in is not None else None,
-                                                         dataset_name)   # RelPN :906
-    if use_ovlp_filter:                                                   # relpn_heads.py:94-105
+    if pairs is not None:                                                 # gt-box branch (:802-810)
+        sbj_inds, obj_inds = np.asarray(pairs[0]).astype(np.int64), np.asarray(pairs[1]).astype(np.int64)
+        rel_rois = np_oracle.rois_union(det_rois[sbj_inds], det_rois[obj_inds])
+    else:
+        sbj_inds, obj_inds, rel_rois = np_oracle.relpn_pairs(det_rois, det_labels if det_labels_in is not None else None,
+                                                             dataset_name)   # RelPN :906
+    if use_ovlp_filter and pairs is None:                                                   # relpn_heads.py:94-105
         sb = (det_rois[sbj_inds][:, 1:] / im_scale).astype(np.float32)
         ob = (det_rois[obj_inds][:, 1:] / im_scale).astype(np.float32)
         ovlp = c_oracle.bbox_pair_overlaps(sb, ob)                        # cython_bbox_rel.pyx:37-77
@@ -242,8 +251,12 @@ def head_forward(sd, blob_conv, feat_map, tmaps, det_rois, im_scale=1.0, f_scale
     spatio_infer = _lin(sd, "spatio_infer_fc.0", sp)                      # :1042
     sem = sem_feat(sd, cls, region_feature, lca, sbj_inds, obj_inds)      # :1044
     # ---- scoring (:1064-1083)
-    s_lab = torch.from_numpy(det_labels[sbj_inds].astype(np.int64) - 1)
-    o_lab = torch.from_numpy(det_labels[obj_inds].astype(np.int64) - 1)
+    if pair_labels is not None:                                           # all_sbj_labels_int32 (:875-876, :1051-1052)
+        s_lab = torch.from_numpy(np.asarray(pair_labels["sbj_labels"]).astype(np.int64) - 1)
+        o_lab = torch.from_numpy(np.asarray(pair_labels["obj_labels"]).astype(np.int64) - 1)
+    else:
+        s_lab = torch.from_numpy(det_labels[sbj_inds].astype(np.int64) - 1)
+        o_lab = torch.from_numpy(det_labels[obj_inds].astype(np.int64) - 1)
     tab = sd["freq_bias.rel_baseline.weight"]
     n_obj = int(round(math.sqrt(tab.shape[0])))
     bias = tab[s_lab * n_obj + o_lab]                                     # sparse_targets_rel.py:67-72

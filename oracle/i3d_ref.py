@@ -104,6 +104,31 @@ def _bottleneck(sd, prefix, x, spatial_stride, dilation, inflate, non_local):
     return out
 
 
+def wiring():
+    """Every Conv3d of the network as this file runs it: name -> (kernel, stride, padding, dilation), and the blocks
+    that carry a non-local block.  tests/test_oracle_goldens_r2.py compares it with the constructor arguments recorded
+    from the reference's own lib/i3d/resnet3d.py (tests/golden/py_i3d_wiring.npz)."""
+    convs = {"conv1": ((5, 7, 7), (2, 2, 2), (2, 3, 3), (1, 1, 1))}
+    nl = []
+    for i, nb in enumerate(STAGE_BLOCKS):
+        for b in range(nb):
+            p = "layer%d.%d" % (i + 1, b)
+            ss = SPATIAL_STRIDES[i] if b == 0 else 1
+            d = DILATIONS[i]
+            if INFLATE[i][b] == 1:
+                convs[p + ".conv1"] = ((3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1))
+            else:
+                convs[p + ".conv1"] = ((1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))
+            convs[p + ".conv2"] = ((1, 3, 3), (1, ss, ss), (0, d, d), (1, d, d))
+            convs[p + ".conv3"] = ((1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1))
+            if b == 0:
+                convs[p + ".downsample"] = ((1, 1, 1), (1, ss, ss), (0, 0, 0), (1, 1, 1))
+            if NON_LOCAL[i][b] == 1:
+                nl.append(p + ".non_local_block")
+    pools = {"maxpool": ((1, 3, 3), (2, 2, 2), (0, 1, 1)), "pool2": ((2, 1, 1), (2, 1, 1), (0, 0, 0))}
+    return convs, nl, pools
+
+
 def i3d_forward(sd, x, return_stages=False, emulate_bf16=False):
     """x (N,3,T,H,W) f32 -> (N,2048,T',H/16,W/16) f32.
 

@@ -132,6 +132,47 @@ def relpn_pairs(det_rois, det_labels=None, dataset_name="vidvrd"):
 # ---------------------------------------------------------------------------
 # Hierarchical box tree: lib/combine_tree/cluster_tree.py:504-649, 400-430
 # ---------------------------------------------------------------------------
+def gt_box_pairs(sbj_gt_boxes, obj_gt_boxes, im_scale, sbj_gt_classes=None, obj_gt_classes=None):
+    """The gt-box branch's host arithmetic, lib/modeling_rel/model_builder_rel.py:773-810 (+ :845-858 when the gt
+    classes are given = use_gt_labels): annotated pairs de-duplicated (np.unique over the int32 8-tuples), boxes
+    de-duplicated into det_rois, pair -> box indices.  Pinned by tests/golden/py_gt_branch.npz (those very lines of
+    the reference, executed on the same inputs by tools/make_goldens_r2.py)."""
+    sbj_boxes = sbj_gt_boxes.copy()                                                  # :776-777
+    obj_boxes = obj_gt_boxes.copy()
+    pair_gt_boxes = np.concatenate((sbj_boxes, obj_boxes), axis=1).astype(np.int32)  # :780
+    pair_gt_boxes, pair_gt_index = np.unique(pair_gt_boxes, return_index=True, axis=0)   # :781
+    sbj_boxes = pair_gt_boxes[:, :4].astype(np.float32)
+    obj_boxes = pair_gt_boxes[:, 4:].astype(np.float32)
+    all_boxes = np.concatenate((sbj_boxes, obj_boxes)).astype(np.int32)              # :787
+    unique_all_boxes, gt_boxes_id = np.unique(all_boxes, return_inverse=True, axis=0)    # :788
+    gt_boxes_id = np.asarray(gt_boxes_id).reshape(-1)
+    sbj_gt_boxes_id = gt_boxes_id[:sbj_boxes.shape[0]]
+    obj_gt_boxes_id = gt_boxes_id[sbj_boxes.shape[0]:]
+    unique_all_boxes = unique_all_boxes.astype(np.float32)
+    im_scale = np.float32(im_scale)
+    sbj_rois = sbj_boxes * im_scale                                                  # :794-796
+    obj_rois = obj_boxes * im_scale
+    all_rois = unique_all_boxes * im_scale
+    rep = 0 * np.ones((sbj_rois.shape[0], 1), dtype=np.float32)                      # blob_utils.ones: float32 (:797-798)
+    rep_det = 0 * np.ones((all_rois.shape[0], 1), dtype=np.float32)
+    sbj_rois = np.hstack((rep, sbj_rois))
+    obj_rois = np.hstack((rep, obj_rois))
+    all_rois = np.hstack((rep_det, all_rois))
+    out = dict(sbj_rois=sbj_rois, obj_rois=obj_rois, rel_rois=rois_union(sbj_rois, obj_rois), det_rois=all_rois,
+               sbj_inds=sbj_gt_boxes_id, obj_inds=obj_gt_boxes_id, pair_gt_index=pair_gt_index)
+    if sbj_gt_classes is not None:                                                   # :845-858
+        sbj_labels = sbj_gt_classes[pair_gt_index]
+        obj_labels = obj_gt_classes[pair_gt_index]
+        all_labels = np.concatenate((sbj_labels, obj_labels))
+        _, gt_labels_id = np.unique(gt_boxes_id, return_index=True)
+        det_labels = all_labels[gt_labels_id]
+        out.update(sbj_labels=sbj_labels, obj_labels=obj_labels, det_labels=det_labels,
+                   sbj_scores=np.ones_like(sbj_labels, dtype=np.float32),
+                   obj_scores=np.ones_like(obj_labels, dtype=np.float32),
+                   det_scores=np.ones_like(det_labels, dtype=np.float32))
+    return out
+
+
 def _get_distance(x, y):
     return ((x - y) ** 2).sum(-1)  # cluster_tree.py:610-611 ('euclid')
 

@@ -25,7 +25,7 @@ def main():
         sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
         i3d_sd = {k[len("Prd_RCNN."):]: v for k, v in sd.items() if k.startswith("Prd_RCNN.")}
         m.to(DEV)
-        outs = m(frames.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2, det_labels=labels, det_scores=scores)
+        outs = m.forward_clips(frames.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2, det_labels=labels, det_scores=scores)
         dbg = m._debug
         tm_hip = dbg["tmaps"].float().permute(0, 1, 4, 2, 3).cpu()
         tm = i3d_forward(i3d_sd, frames[:1].permute(0, 2, 1, 3, 4).contiguous())[0].permute(1, 0, 2, 3).contiguous()

@@ -121,7 +121,7 @@ def test_clip_to_triplets_vs_fp32_oracle(regime, B, T, n, with_labels):
     i3d_sd = {k[len("Prd_RCNN."):]: v for k, v in sd.items() if k.startswith("Prd_RCNN.")}
     sd_floor = operand_rounded_sd(i3d_sd)
     m.to(DEV)
-    outs = m(frames.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2, det_labels=labels, det_scores=scores)
+    outs = m.forward_clips(frames.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2, det_labels=labels, det_scores=scores)
     tm_hip = m._debug["tmaps"].float().permute(0, 4, 1, 2, 3).cpu()                  # (B,C,T',h,w)
     stage_hip = hip_stages(m, frames.to(DEV))
     poff = 0

@@ -150,3 +150,29 @@ def test_i3d_graph_replay_equals_eager():
     buf = m.graph_clip_buffer(a)
     buf.copy_(b)
     assert torch.equal(m.forward_ndhwc_graphed(buf), eb)
+
+
+def test_backbone_is_deterministic_at_bench_size():
+    """Race screen at the bench workload's size (8 clips x 32 frames x 224^2: 3136 stem workgroups, every launch rule of
+    the bench): the backbone has no atomics and fixed summation orders, so repeated runs on fresh clips (cold caches)
+    must be bit-identical, launch by launch for the stem.  An LDS-DMA stage read too early shows up here as a few
+    differing output channels in a few workgroups (it did, in the f32 stem, before its K-loop drained every stage)."""
+    from trace_amd import ops
+    m = make_model().to(DEV)
+    w, b, kwp = m._stem_weights()
+    for trial in range(3):
+        g = torch.Generator().manual_seed(100 + trial)
+        clip = (torch.randn((8, 32, 3, 224, 224), generator=g) * 50).to(DEV)
+        stems, outs = [], []
+        for rep in range(4):
+            stems.append(ops.conv3d_stem_f32(clip, True, w, b, 4, (8, 112, 112)).clone())
+            outs.append(m.forward_ndhwc(clip, in_ntchw=True).clone())
+        torch.cuda.synchronize()
+        for rep in range(1, 4):
+            assert torch.equal(stems[0], stems[rep]), ("stem", trial, rep, int((stems[0] != stems[rep]).sum()))
+            assert torch.equal(outs[0], outs[rep]), ("backbone", trial, rep, int((outs[0] != outs[rep]).sum()))
+        # the f32 stem equals the two-launch path (padded bf16 copy + LDS-DMA patch) bit for bit
+        xp = ops.clip_to_ndhwc(clip, True, 4, (2, 2, 3, 3, 3, 5))
+        ref = ops.conv3d_stem(xp, w, b, 5, 7, 8, (4, 2, 2), (8, 112, 112), alg_k=735)
+        assert torch.equal(stems[0], ref)
+        del clip, stems, outs, xp, ref

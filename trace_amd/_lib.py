@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrace_amd.so")
+# TRACE_AMD_LIB: load another build of the same library (A/B diagnostics); the default is the in-tree build
+LIB_PATH = os.environ.get("TRACE_AMD_LIB") or os.path.join(_HERE, "lib", "libtrace_amd.so")
 
 c_int = ctypes.c_int
 c_float = ctypes.c_float
@@ -43,6 +44,7 @@ SIGNATURES = {
     "trace_layernorm_act_bf16": (c_int, [P, c_int, c_int, P, P, c_float, c_int, P, P]),
     "trace_gather_add_act_bf16": (c_int, [P, P, P, c_longlong, c_int, c_int, P, P]),
     "trace_pair_assemble": (c_int, [P, P, P, P, c_int, P, P, c_int, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P, P]),
+    "trace_pair_assemble_ex": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P, P]),
     "trace_temporal_attention_ex": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "trace_nms_workspace_bytes": (c_size_t, [c_int]),
     "trace_nms": (c_int, [P, P, c_int, c_float, c_int, P, P, P, c_size_t, P]),

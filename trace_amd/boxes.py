@@ -199,6 +199,17 @@ def prepare_det_rois(rois, cls_scores, bbox_pred, im_info, score_thresh=0.05, nm
     return torch.cat(out_r), torch.cat(out_l), torch.cat(out_s), torch.cat(out_i)
 
 
+def rois_union_np(rois1, rois2):
+    """lib/utils_rel/boxes_rel.py:100-106 on the host (the pair lists are built there): (P,5) x (P,5) -> (P,5)."""
+    import numpy as np
+    assert (rois1[:, 0] == rois2[:, 0]).all()
+    xmin = np.minimum(rois1[:, 1], rois2[:, 1])
+    ymin = np.minimum(rois1[:, 2], rois2[:, 2])
+    xmax = np.maximum(rois1[:, 3], rois2[:, 3])
+    ymax = np.maximum(rois1[:, 4], rois2[:, 4])
+    return np.vstack((rois1[:, 0], xmin, ymin, xmax, ymax)).transpose()
+
+
 def relpn_pair_indices(n, det_labels=None, dataset="vidvrd"):
     """Host-side pair enumeration of single_scale_relpn_outputs.forward (relpn_heads.py:71-84,39-55):
     all ordered pairs without self pairs; on Action Genome ('ag' in the dataset name) only persons

@@ -41,8 +41,10 @@ def _cluster_layer(feat, l, r, cluster_num):
     return centres, rest, owner
 
 
-def build_tree(leaf_boxes, max_tree_height=7, partition=2):
-    """leaf_boxes (n,4) float32 -> dict(parent, level_off, boxes, n_leaf) for one clip."""
+def build_tree(leaf_boxes, max_tree_height=7, partition=2, with_layers=False):
+    """leaf_boxes (n,4) float32 -> dict(parent, level_off, boxes, n_leaf) for one clip.  with_layers: also
+    `layers`, the reference's own structure (cluster_tree.py:511, :586-593): one dict per layer,
+    {new node: [its centre, then the joined nodes in the order they were assigned]}."""
     n = leaf_boxes.shape[0]
     if n <= 0:
         raise ValueError("a clip needs at least one box")
@@ -63,10 +65,16 @@ def build_tree(leaf_boxes, max_tree_height=7, partition=2):
     feat[:n] = leaf_boxes
     parent = np.full(total, -1, np.int32)
     level_off = [0, n]
+    layers = []
     l, r = 0, n - 1
     for k in sizes:
         centres, rest, owner = _cluster_layer(feat, l, r, k)
         new_ids = np.arange(r + 1, r + 1 + k)
+        if with_layers:
+            d = {int(new_ids[i]): [int(centres[i])] for i in range(k)}
+            for i in range(len(rest)):
+                d[int(new_ids[owner[i]])].append(int(rest[i]))
+            layers.append(d)
         parent[centres] = new_ids
         nb = feat[centres].copy()                        # hull of each group (:617-628): min / max are exact
         if len(rest):
@@ -79,7 +87,30 @@ def build_tree(leaf_boxes, max_tree_height=7, partition=2):
         feat[r + 1:r + 1 + k] = nb
         l, r = r + 1, r + k
         level_off.append(r + 1)
-    return dict(parent=parent, level_off=level_off, boxes=feat, n_leaf=n)
+    out = dict(parent=parent, level_off=level_off, boxes=feat, n_leaf=n)
+    if with_layers:
+        out["layers"] = layers
+    return out
+
+
+def adjacency_and_link(n_tree, layers):
+    """cluster_tree.py:400-430 get_A_and_link for one clip: dense child->parent matrix A (A[son, fa] = 1), its
+    transpose A_T and the ancestor table `link` (n_tree, levels + 1; -1 where undefined) - what the reference's
+    callers receive in the 13-tuple of cluster_tree3d.forward.  The HIP path itself uses the parent / CSR arrays."""
+    A_T = np.zeros((n_tree, n_tree), np.float32)
+    A = np.zeros((n_tree, n_tree), np.float32)
+    rev = layers[::-1]
+    link = -np.ones((n_tree, len(rev) + 1), dtype=np.int64)
+    link[n_tree - 1, len(rev)] = n_tree - 1
+    j = len(rev) - 1
+    for layer in rev:
+        for fa, son in layer.items():
+            A_T[fa, son] = 1.0
+            A[son, fa] = 1.0
+            link[son, j + 1:] = link[fa, j + 1:]
+            link[son, j] = son
+        j -= 1
+    return A, A_T, link
 
 
 def layer_sizes(n, max_tree_height=7, partition=2):

@@ -28,6 +28,7 @@ class TraceConfig:
     LOW_FEAT_DIM: int = 256
     DETECTIONS_PER_IM: int = 100
     TEST_NMS: float = 0.5
+    TEST_SCORE_THRESH: float = 0.05   # lib/core/config.py TEST.SCORE_THRESH
     dataset: str = "vidvrd"
 
 
@@ -38,3 +39,19 @@ def vidvrd_config():
 def ag_config():
     """Action Genome dims (tools/test_net_rel.py:166-170; configs/ag/res101xi3d50_dc5_2d.yaml)."""
     return TraceConfig(NUM_CLASSES=37, NUM_PRD_CLASSES=26, RESIZE_HIDDEN_DIM=1, USE_OVLP_FILTER=True, dataset="ag")
+
+
+# The reference's modules read a global `cfg` (lib/core/config.py:40); constructors here take `cfg=` explicitly and
+# fall back to this process-wide default, which a caller may replace (`set_cfg`) before building modules.
+_DEFAULT = [None]
+
+
+def get_cfg():
+    if _DEFAULT[0] is None:
+        _DEFAULT[0] = TraceConfig()
+    return _DEFAULT[0]
+
+
+def set_cfg(cfg):
+    _DEFAULT[0] = cfg
+    return cfg

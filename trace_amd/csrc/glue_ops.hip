@@ -85,18 +85,21 @@ __global__ __launch_bounds__(256) void gather_add_act_kernel(const float* __rest
 // One workgroup per pair p (subject X[p], object Y[p], indices into the step's detection list).
 __global__ __launch_bounds__(128) void pair_assemble_kernel(
     const int64_t* __restrict__ det_labels, const float* __restrict__ det_scores, const int64_t* __restrict__ X,
-    const int64_t* __restrict__ Y, const float* __restrict__ low_s, const float* __restrict__ low_o, int wl,
+    const int64_t* __restrict__ Y, const int64_t* __restrict__ pls, const int64_t* __restrict__ plo,
+    const float* __restrict__ pss, const float* __restrict__ pso, const float* __restrict__ low_s,
+    const float* __restrict__ low_o, int wl,
     const float* __restrict__ part_s, const float* __restrict__ part_o, int wp, const float* __restrict__ freq,
     int n_rel, int n_obj, int64_t* __restrict__ sbj_lab, int64_t* __restrict__ obj_lab, float* __restrict__ sbj_sc,
     float* __restrict__ obj_sc, float* __restrict__ so_bias, float* __restrict__ so_part) {
   const long long p = blockIdx.x;
   const long long s = X[p], o = Y[p];
-  const int64_t ls = det_labels[s], lo = det_labels[o];
+  // per-pair labels / scores when given (use_gt_labels, model_builder_rel.py:844-858), else gathered per roi
+  const int64_t ls = pls ? pls[p] : det_labels[s], lo = plo ? plo[p] : det_labels[o];
   if (threadIdx.x == 0) {
     sbj_lab[p] = ls;   // relpn_heads.py:113-116
     obj_lab[p] = lo;
-    sbj_sc[p] = det_scores[s];
-    obj_sc[p] = det_scores[o];
+    sbj_sc[p] = pss ? pss[p] : det_scores[s];
+    obj_sc[p] = pso ? pso[p] : det_scores[o];
   }
   for (int j = threadIdx.x; j < wl; j += blockDim.x)  // model_builder_rel.py:1662 (the region term joins later)
     so_bias[p * wl + j] = low_s[s * wl + j] + low_o[o * wl + j];
@@ -151,20 +154,32 @@ extern "C" int trace_gather_add_act_bf16(const float* a, const float* b, const i
   return check_launch("gather_add_act_bf16");
 }
 
+extern "C" int trace_pair_assemble_ex(const int64_t* det_labels, const float* det_scores, const int64_t* X,
+                                      const int64_t* Y, int P, const int64_t* pair_sbj_lab, const int64_t* pair_obj_lab,
+                                      const float* pair_sbj_sc, const float* pair_obj_sc, const float* low_s,
+                                      const float* low_o, int wl, const float* part_s, const float* part_o, int wp,
+                                      const float* freq, int n_rel, int n_obj, int64_t* sbj_lab, int64_t* obj_lab,
+                                      float* sbj_sc, float* obj_sc, float* so_bias, float* so_part, trace_stream_t stream) {
+  TRACE_REQUIRE(P >= 0 && wl > 0 && wp > 0 && n_rel >= 0 && n_rel <= wp && n_obj >= 0, "pair_assemble: bad shape");
+  if (P == 0) return 0;
+  TRACE_REQUIRE(X && Y && low_s && low_o && part_s && part_o && sbj_lab && obj_lab && sbj_sc && obj_sc && so_bias && so_part,
+                "pair_assemble: null pointer");
+  TRACE_REQUIRE((det_labels || (pair_sbj_lab && pair_obj_lab)) && (det_scores || (pair_sbj_sc && pair_obj_sc)),
+                "pair_assemble: labels / scores must come per roi or per pair");
+  hipLaunchKernelGGL(pair_assemble_kernel, dim3(P), dim3(128), 0, (hipStream_t)stream, det_labels, det_scores, X, Y,
+                     pair_sbj_lab, pair_obj_lab, pair_sbj_sc, pair_obj_sc, low_s, low_o, wl, part_s, part_o, wp, freq, n_rel,
+                     n_obj, sbj_lab, obj_lab, sbj_sc, obj_sc, so_bias, so_part);
+  return check_launch("pair_assemble");
+}
+
 extern "C" int trace_pair_assemble(const int64_t* det_labels, const float* det_scores, const int64_t* X,
                                    const int64_t* Y, int P, const float* low_s, const float* low_o, int wl,
                                    const float* part_s, const float* part_o, int wp, const float* freq, int n_rel,
                                    int n_obj, int64_t* sbj_lab, int64_t* obj_lab, float* sbj_sc, float* obj_sc,
                                    float* so_bias, float* so_part, trace_stream_t stream) {
-  TRACE_REQUIRE(P >= 0 && wl > 0 && wp > 0 && n_rel >= 0 && n_rel <= wp && n_obj >= 0, "pair_assemble: bad shape");
-  if (P == 0) return 0;
-  TRACE_REQUIRE(det_labels && det_scores && X && Y && low_s && low_o && part_s && part_o && sbj_lab && obj_lab &&
-                    sbj_sc && obj_sc && so_bias && so_part,
-                "pair_assemble: null pointer");
-  hipLaunchKernelGGL(pair_assemble_kernel, dim3(P), dim3(128), 0, (hipStream_t)stream, det_labels, det_scores, X, Y,
-                     low_s, low_o, wl, part_s, part_o, wp, freq, n_rel, n_obj, sbj_lab, obj_lab, sbj_sc, obj_sc, so_bias,
-                     so_part);
-  return check_launch("pair_assemble");
+  TRACE_REQUIRE(P == 0 || (det_labels && det_scores), "pair_assemble: null pointer");
+  return trace_pair_assemble_ex(det_labels, det_scores, X, Y, P, nullptr, nullptr, nullptr, nullptr, low_s, low_o, wl, part_s,
+                                part_o, wp, freq, n_rel, n_obj, sbj_lab, obj_lab, sbj_sc, obj_sc, so_bias, so_part, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

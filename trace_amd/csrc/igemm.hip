@@ -983,8 +983,15 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
 
 #pragma unroll
   for (int ks = 0; ks < ST_KSTEPS; ++ks) {
-    if (ks + 1 < ST_KSTEPS) wait_vmcnt<2>();   // the newest weight stage may stay in flight
-    else wait_vmcnt<0>();
+    // Drain EVERY weight stage in flight, not only step ks's: a stage is then read one whole K-step after the wait
+    // that retired it (step ks's stage was retired by the wait of step ks-1; the stage still loading during a step is
+    // the one issued after its barrier).  With the counted wait this loop used first - vmcnt(2): "step ks's stage has
+    // landed, the next may stay in flight", read right behind the barrier - waves read bytes of another wave's DMA
+    // that had been counted done but were not in LDS yet: a few wrong output channels per 8 x 16 positions in a few of
+    // 3136 workgroups, only at B = 8 / 32 frames, run-dependent (race screen: tests/test_i3d_gpu.py::
+    // test_backbone_is_deterministic_at_bench_size).  The generic loops put six DMA issues between barrier and first
+    // fragment read; this kernel only two.
+    wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     if (ks + 2 < ST_KSTEPS) issue_a((ks + 2) % 3, ks + 2 == ST_KSTEPS - 1);
     const int abase = (ks % 3) * ST_ASTAGE;

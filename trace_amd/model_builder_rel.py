@@ -33,8 +33,9 @@ from . import boxes as box_ops
 from . import cluster_tree as ct
 from . import ops
 from .config import TraceConfig, vidvrd_config
-from .heads import (cluster_tree3d, fast_rcnn_outputs, init_msra_conv, init_xavier, roi_2mlp_head,
-                    xavier_fill)
+from .heads import (PackedLinears, cluster_tree3d, fast_rcnn_outputs, ffn12_weights, init_msra_conv, init_xavier,
+                    roi_2mlp_head, tree_gru_weights, xavier_fill)
+from .roi_xform import add_rel_multilevel_rois, roi_feature_transform
 from .resnet3d import _PACK_EPOCH, ResNet3d, i3d_dc5_config
 
 
@@ -122,7 +123,7 @@ class _Upload:
             host_u8[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
 
 
-class Generalized_RCNN(nn.Module):
+class Generalized_RCNN(PackedLinears):
     def __init__(self, cfg: TraceConfig = None):
         super().__init__()
         cfg = cfg or vidvrd_config()
@@ -209,6 +210,12 @@ class Generalized_RCNN(nn.Module):
         # branch, tree-GRU, query GEMMs); True: beside the backbone (measured no faster than the fused launch: 2.869 vs
         # 2.852 ms/step); False: one fused launch after the tree-GRU
         self.split_pair_pool = "tail"
+        # The three networks around the hot path stay pluggable callables: `forward` calls them exactly
+        # where the reference does.  Conv_Body(data) -> blob_conv (:702), Prd_RCNN2D(frame) -> feat_map (:1006-1007)
+        # [(1,2048,H/16,W/16) f32 NCHW or (1,H/16,W/16,2048) bf16], RPN(blob_conv, im_info, roidb) -> rpn_ret (:733).
+        self.Conv_Body = None
+        self.Prd_RCNN2D = None
+        self.RPN = None
         # a checkpoint loaded into a SUB-module (model.Box_Head.load_state_dict(..)) never reaches this class's
         # load_state_dict: every sub-module drops the packed weights (and the captured graphs, through the epoch in
         # their keys) from a post-hook of its own load
@@ -231,119 +238,13 @@ class Generalized_RCNN(nn.Module):
         self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
         return super().load_state_dict(*a, **k)
 
-    def _cached(self, key, make):
-        v = self._pk.get(key)
-        if v is None:
-            with torch.no_grad():
-                v = make()
-            self._pk[key] = v
-        return v
-
-    @staticmethod
-    def _pad_k(w, mult=8):
-        k = w.shape[1]
-        if k % mult:
-            w = F.pad(w, (0, mult - k % mult))
-        return w
-
-    @staticmethod
-    def _pad_n(w, b, mult=8):
-        n = w.shape[0]
-        if n % mult:
-            w = F.pad(w, (0, 0, 0, mult - n % mult))
-            if b is not None:
-                b = F.pad(b, (0, mult - n % mult))
-        return w, b
-
-    def _lin_w(self, key, layers, perm_hw_c=None, pad_bias=0.0):
-        """Packed (W bf16 (Np,Kp), bias f32 (Np) | None, N) of one Linear / 1x1 conv or several
-        stacked along the output dimension.  `pad_bias` fills the bias of the padding rows (Np > N)."""
-        def make():
-            ws, bs = [], []
-            for l in layers:
-                w = l.weight.detach().float().reshape(l.weight.shape[0], -1)
-                if perm_hw_c is not None:  # columns (C, ph, pw) -> (ph, pw, C): channels-last pooled rows
-                    c, hw = perm_hw_c
-                    w = w.view(w.shape[0], c, hw).permute(0, 2, 1).reshape(w.shape[0], -1)
-                ws.append(w)
-                bs.append(l.bias.detach().float() if l.bias is not None else torch.zeros(w.shape[0], device=w.device))
-            w = torch.cat(ws, 0)
-            b = torch.cat(bs, 0) if (any(l.bias is not None for l in layers) or pad_bias != 0.0) else None
-            n = w.shape[0]
-            w, b = self._pad_n(self._pad_k(w), b)
-            if b is not None and pad_bias != 0.0:
-                b[n:] = pad_bias
-            return w.to(torch.bfloat16).contiguous(), (b.contiguous() if b is not None else None), n
-        return self._cached(key, make)
-
-    def _stack_w(self, key, layers):
-        """Same-shaped Linears as ONE batched GEMM operand: (W bf16 (b,Np,Kp), bias f32 (b,Np), N)."""
-        def make():
-            ws, bs = [], []
-            for l in layers:
-                w = l.weight.detach().float().reshape(l.weight.shape[0], -1)
-                b = l.bias.detach().float() if l.bias is not None else torch.zeros(w.shape[0], device=w.device)
-                w, b = self._pad_n(self._pad_k(w), b)
-                ws.append(w)
-                bs.append(b)
-            return torch.stack(ws).to(torch.bfloat16).contiguous(), torch.stack(bs).contiguous(), layers[0].weight.shape[0]
-        return self._cached(key, make)
-
-    def _gemm(self, x, key, layers, perm_hw_c=None, keep_pad=False, pad_bias=0.0, tiled=False, **kw):
-        """x (M,K) -> (M,N) through the bf16 MFMA GEMM; pads K / slices N as needed (keep_pad: keep the
-        N-padding columns).  With out2=... returns (y, y2).  tiled: keep the packed weights in the pre-tiled
-        weight-streaming layout (ops.tile_weights) - the 100352-wide FCs."""
-        if tiled and (key + "/tiled") in self._pk:
-            w, b, n = self._pk[key + "/tiled"]
-            kw["b_tiled"] = True
-        else:
-            w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)
-            if tiled and w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0:
-                w = ops.tile_weights(w)
-                self._pk[key + "/tiled"] = (w, b, n)
-                del self._pk[key]                    # only the tiled copy stays resident
-                kw["b_tiled"] = True
-        x = _bf(x)
-        if x.shape[-1] != w.shape[1]:
-            x = F.pad(x, (0, w.shape[1] - x.shape[-1]))
-        if x.stride(-1) != 1:
-            x = x.contiguous()
-        y = ops.gemm_nt(x, w, bias=b, **kw)
-        if keep_pad or w.shape[0] == n:
-            return y
-        if isinstance(y, tuple):
-            return tuple(t[..., :n] for t in y)
-        return y[..., :n]
-
     def _tree_weights(self):
-        def make():
-            out = []
-            for tm in self.cluster_tree3d.tree_message_passing_list:
-                d = {}
-                for sfx in ("", "d"):
-                    for n in ("Wz", "Wr", "Wh", "Uz", "Ur", "Uh"):
-                        d[n + sfx] = getattr(tm, n + sfx)[0].weight.detach().float().t().contiguous()
-                    d["bz" + sfx] = getattr(tm, "Uz" + sfx)[0].bias.detach().float().contiguous()
-                    d["br" + sfx] = getattr(tm, "Ur" + sfx)[0].bias.detach().float().contiguous()
-                out.append(d)
-            return out
-        return self._cached("tree", make)
+        tms = self.cluster_tree3d.tree_message_passing_list
+        return self._cached("tree", lambda: tree_gru_weights(tms), [p for tm in tms for p in tm.parameters()])
 
     def _ffn12_w(self):
-        """FFN1(h) + FFN2(hd) of every group (cluster_tree.py:203) as ONE GEMM over [h | hd]: block-diagonal
-        weight (fc, 2*fc) - group g reads h[:, g] and hd[:, g] only - with bias b1 + b2."""
-        def make():
-            tms = self.cluster_tree3d.tree_message_passing_list
-            G = len(tms)
-            gw, hd = tms[0].FFN1[0].weight.shape
-            w = torch.zeros((G * gw, 2 * G * hd), device=tms[0].FFN1[0].weight.device)
-            bs = []
-            for g, tm in enumerate(tms):
-                w[g * gw:(g + 1) * gw, g * hd:(g + 1) * hd] = tm.FFN1[0].weight.detach().float()
-                w[g * gw:(g + 1) * gw, G * hd + g * hd:G * hd + (g + 1) * hd] = tm.FFN2[0].weight.detach().float()
-                bs.append(tm.FFN1[0].bias.detach().float() + tm.FFN2[0].bias.detach().float())
-            return w.to(torch.bfloat16).contiguous(), torch.cat(bs).contiguous()
-        return self._cached("ffn12", make)
+        tms = self.cluster_tree3d.tree_message_passing_list
+        return self._cached("ffn12", lambda: ffn12_weights(tms), [p for tm in tms for p in tm.parameters()])
 
     # ------------------------------------------------------------------ host-side roi lists
     @staticmethod
@@ -360,9 +261,9 @@ class Generalized_RCNN(nn.Module):
         return rois.reshape(-1, 5)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
-                det_labels=None, det_scores=None):
-        """Inference on B clips.
+    def forward_clips(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
+                      det_labels=None, det_scores=None, pairs=None, pair_labels=None):
+        """Inference on B clips: the batched hot path behind `forward` (which keeps the reference's one-clip signature).
           all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688)
           blob_conv  (B,2048,H/16,W/16) f32 NCHW or (B,H/16,W/16,2048) bf16 — Conv_Body(data) (:702)
           feat_map   same layouts — Prd_RCNN2D(cur frame) (:1006-1007)
@@ -372,6 +273,11 @@ class Generalized_RCNN(nn.Module):
                      detected-box branch's prepare_det_rois output (:912-915).  They then feed RelPN (on Action
                      Genome only persons, label <= 1, are subjects: relpn_heads.py:71-77) and the pair labels /
                      scores; without them labels / scores are the Box_Outs argmax (:900-904).
+          pairs      optional list of B (sbj_inds, obj_inds) integer arrays into the clip's rois: the relation proposals
+                     themselves - the gt-box branch (:772-888) pairs the de-duplicated gt boxes as annotated instead of
+                     enumerating all ordered pairs (RelPN, :906).
+          pair_labels optional list of B dicts(sbj_labels, obj_labels [1-based], sbj_scores, obj_scores), one entry per
+                     pair: `use_gt_labels` (:844-858) - per-pair labels / scores that also index the frequency bias.
         Returns a list of B dicts with the reference's return keys (:1162-1182)."""
         if self.training:
             raise ValueError('You should call this function only on inference. '
@@ -379,7 +285,7 @@ class Generalized_RCNN(nn.Module):
         with torch.no_grad():
             dev = all_frames.device
             prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale,
-                                   det_labels, det_scores)
+                                   det_labels, det_scores, pairs, pair_labels)
             if self.graph_step and self.overlap_steps and ops.IGEMM_TRACE is None:
                 return self._replay_overlap(all_frames, blob_conv, feat_map, prep, topk, prd_k)
             if self._ov_pending is not None:
@@ -391,6 +297,193 @@ class Generalized_RCNN(nn.Module):
                 res = self._device_forward(all_frames, self._nhwc(blob_conv), self._nhwc(feat_map), prep, dv, topk,
                                            prd_k, self.graph_backbone)
             return self._make_outs(prep, res, topk, prd_k)
+
+
+    # ------------------------------------------------------------------ reference signature (one clip per call)
+    @staticmethod
+    def _unwrap(v):
+        """The harness hands every input over as a one-element list for DataParallel's scatter
+        (lib/core/test_rel.py:82-113); without that wrapper the elements arrive still wrapped."""
+        while isinstance(v, (list, tuple)) and len(v) == 1:
+            v = v[0]
+        return v
+
+    @staticmethod
+    def _dataset_name(v, default):
+        """`dataset_name` arrives serialized (utils/blob.py:165-176: the pickled string as a float32 array)."""
+        if v is None:
+            return default
+        if isinstance(v, str):
+            return v
+        import io
+        import pickle
+
+        class _StrOnly(pickle.Unpickler):           # a pickled str needs no globals: refuse anything else
+            def find_class(self, module, name):
+                raise pickle.UnpicklingError("dataset_name: unexpected pickled object")
+        raw = np.asarray(v.cpu() if torch.is_tensor(v) else v).astype(np.uint8).tobytes()
+        out = _StrOnly(io.BytesIO(raw)).load()
+        if not isinstance(out, str):
+            raise ValueError("dataset_name must deserialize to a string")
+        return out
+
+    def roi_feature_transform(self, blobs_in, rpn_ret, blob_rois='rois', method='RoIAlign', resolution=7,
+                              spatial_scale=1. / 16., sampling_ratio=0):
+        """model_builder_rel.py:1342-1396 (FPN-aware dispatch or the single-level path)."""
+        return roi_feature_transform(blobs_in, rpn_ret, blob_rois, method, resolution, spatial_scale, sampling_ratio)
+
+    @staticmethod
+    def gt_box_pairs(roidb, im_scale, use_gt_labels=False):
+        """The gt-box branch's host arithmetic (model_builder_rel.py:776-810, 844-858): annotated (subject, object) box
+        pairs de-duplicated by np.unique over the int32 8-tuples, the boxes themselves de-duplicated into det_rois,
+        pair -> box indices, and (use_gt_labels) the labels / scores that come with the annotation.
+        Returns dict(det_rois (n,5) f32 scaled, sbj_inds, obj_inds (P,), sbj_rois, obj_rois (P,5), rel_rois (P,5),
+        pair_gt_index, and with use_gt_labels: sbj_labels, obj_labels, det_labels [0-based], *_scores)."""
+        sbj_boxes = roidb['sbj_gt_boxes'].copy()
+        obj_boxes = roidb['obj_gt_boxes'].copy()
+        pair_gt_boxes = np.concatenate((sbj_boxes, obj_boxes), axis=1).astype(np.int32)
+        pair_gt_boxes, pair_gt_index = np.unique(pair_gt_boxes, return_index=True, axis=0)
+        sbj_boxes = pair_gt_boxes[:, :4].astype(np.float32)
+        obj_boxes = pair_gt_boxes[:, 4:].astype(np.float32)
+        all_boxes = np.concatenate((sbj_boxes, obj_boxes)).astype(np.int32)
+        unique_all_boxes, gt_boxes_id = np.unique(all_boxes, return_inverse=True, axis=0)
+        gt_boxes_id = np.asarray(gt_boxes_id).reshape(-1)           # numpy 2 returns the inverse shaped like the input
+        sbj_id = gt_boxes_id[:sbj_boxes.shape[0]]
+        obj_id = gt_boxes_id[sbj_boxes.shape[0]:]
+        unique_all_boxes = unique_all_boxes.astype(np.float32)
+        im_scale = np.float32(im_scale)
+        zeros = lambda k: np.zeros((k, 1), np.float32)
+        sbj_rois = np.hstack((zeros(len(sbj_boxes)), sbj_boxes * im_scale))
+        obj_rois = np.hstack((zeros(len(obj_boxes)), obj_boxes * im_scale))
+        all_rois = np.hstack((zeros(len(unique_all_boxes)), unique_all_boxes * im_scale))
+        out = dict(det_rois=all_rois.astype(np.float32), sbj_inds=sbj_id, obj_inds=obj_id, sbj_rois=sbj_rois.astype(np.float32),
+                   obj_rois=obj_rois.astype(np.float32), rel_rois=box_ops.rois_union_np(sbj_rois, obj_rois),
+                   pair_gt_index=pair_gt_index)
+        if use_gt_labels:
+            sbj_labels = roidb['sbj_gt_classes'][pair_gt_index]     # start from 0
+            obj_labels = roidb['obj_gt_classes'][pair_gt_index]
+            all_labels = np.concatenate((sbj_labels, obj_labels))
+            _, gt_labels_id = np.unique(gt_boxes_id, return_index=True)
+            det_labels = all_labels[gt_labels_id]
+            out.update(sbj_labels=sbj_labels, obj_labels=obj_labels, det_labels=det_labels,
+                       sbj_scores=np.ones_like(sbj_labels, dtype=np.float32),
+                       obj_scores=np.ones_like(obj_labels, dtype=np.float32),
+                       det_scores=np.ones_like(det_labels, dtype=np.float32))
+        return out
+
+    def forward(self, data, all_frames, im_info, pre_processed_frames_rpn_ret=None, pre_processed_temporal_roi=None,
+                do_vis=False, dataset_name=None, file_name=None, roidb=None, use_gt_labels=False, bf_cur_len=None,
+                f_scale=None, **rpn_kwargs):
+        """The reference's `Generalized_RCNN.forward` (model_builder_rel.py:648-662 -> `_forward` :664-1204), inference:
+          data (1,3,H,W) f32 GPU key frame; all_frames (1,T,3,h,w) f32 GPU; im_info (1,3) [H,W,scale] (CPU);
+          roidb dict with sbj_gt_boxes / obj_gt_boxes (/ *_gt_classes): the gt-box branch (:772-888);
+          pre_processed_frames_rpn_ret {rois (n,5), labels_int32 [(n,)], (prd_category, score)}: pre-computed boxes
+          (:704-731, :892-907); otherwise RPN + prepare_det_rois + RelPN (:733, :908-935).
+        Returns the reference's dict (:1162-1182, :1195-1196); the entries the reference returns as numpy arrays and its
+        harness reads through DataParallel's gather (`.data.cpu().numpy()`, lib/core/test_rel.py:120-125) are CPU
+        tensors here, so `im_get_det_rels` works on the result without the DataParallel wrapper."""
+        if self.training:
+            raise NotImplementedError("trace_amd implements the inference path; call .eval() "
+                                      "(the reference's helpers raise likewise outside inference, :91-104)")
+        u = self._unwrap
+        data, all_frames, im_info, roidb = u(data), u(all_frames), u(im_info), u(roidb)
+        rpn_pre, use_gt_labels = u(pre_processed_frames_rpn_ret), bool(u(use_gt_labels))
+        bf_cur_len, f_scale = u(bf_cur_len), u(f_scale)
+        cfg = self.cfg
+        dataset_name = self._dataset_name(u(dataset_name), cfg.dataset)
+        if torch.is_tensor(bf_cur_len):
+            bf_cur_len = int(bf_cur_len.item())
+        if torch.is_tensor(f_scale):
+            f_scale = float(f_scale.item())
+        if bf_cur_len is None:
+            bf_cur_len = all_frames.shape[1] // 2
+        f_scale = 1.0 if f_scale is None else float(f_scale)
+        if all_frames.shape[0] != 1:
+            raise ValueError("forward() takes one clip per call as the reference does (relpn_heads.py:67); "
+                             "forward_clips() is the batched entry")
+        if self.Conv_Body is None or self.Prd_RCNN2D is None:
+            raise RuntimeError("Generalized_RCNN.forward needs model.Conv_Body and model.Prd_RCNN2D (the 2-D conv bodies, "
+                               "model_builder_rel.py:702,1006-1007): assign callables, or call forward_clips() with their outputs")
+        im_info_np = np.asarray(im_info.detach().cpu().numpy() if torch.is_tensor(im_info) else im_info, np.float32)
+        im_scale = float(im_info_np[0, 2])
+        dev = all_frames.device
+        with torch.no_grad():
+            blob_conv = self.Conv_Body(data)                                                     # :702
+            feat_map = self.Prd_RCNN2D(all_frames[:, int(bf_cur_len)])                           # :1006-1007
+            pairs = pair_labels = det_labels = det_scores = None
+            bad_gt = roidb is None or (len(roidb['sbj_gt_boxes']) + len(roidb['obj_gt_boxes'])) <= 0   # :767-771
+            if not bad_gt:
+                # ---- gt-box branch (:772-888).  Box_Head / S_Head / O_Head pool sbj_rois / obj_rois / det_rois there;
+                # sbj_rois[p] IS det_rois[sbj_inds[p]] bit for bit (same int32 box times the same f32 scale), so the
+                # per-pair pooled rows and head outputs are gathers of the per-box ones: pooled once per unique box
+                gt = self.gt_box_pairs(roidb, im_info_np[0, 2], use_gt_labels)
+                det_rois = gt["det_rois"]
+                pairs = [(gt["sbj_inds"], gt["obj_inds"])]
+                if use_gt_labels:
+                    det_labels, det_scores = [gt["det_labels"].astype(np.int64) + 1], [gt["det_scores"]]
+                    pair_labels = [dict(sbj_labels=gt["sbj_labels"].astype(np.int64) + 1,
+                                        obj_labels=gt["obj_labels"].astype(np.int64) + 1,
+                                        sbj_scores=gt["sbj_scores"], obj_scores=gt["obj_scores"])]
+            elif rpn_pre is not None and dataset_name.find('vidvrd') >= 0:
+                # ---- pre-computed boxes (:704-731, :892-907); the reference scales the caller's array in place (:724)
+                if dataset_name.find('vid') >= 0:
+                    rpn_pre['rois'][:, 1:] *= float(im_info_np[0, -1])
+                det_rois = np.asarray(rpn_pre['rois'], np.float32)
+                if 'prd_category' in rpn_pre:
+                    det_labels = [np.asarray(rpn_pre['prd_category']).astype(np.int64)]
+                    det_scores = [np.amax(np.asarray(rpn_pre['score'], np.float32)[:, 1:], axis=1)]
+            else:
+                # ---- detected boxes (:733, :908-935): RPN -> Box_Head / Box_Outs on every proposal -> per-class NMS
+                if self.RPN is None:
+                    raise RuntimeError("Generalized_RCNN.forward: no gt boxes and no pre-computed boxes were given, and "
+                                       "model.RPN is not set (RPN + generate_proposals: model_builder_rel.py:733)")
+                rpn_ret = self.RPN(blob_conv, im_info, roidb)
+                box_feat = self.Box_Head(blob_conv, rpn_ret, use_relu=True)                      # :742
+                cls_score, bbox_pred = self.Box_Outs(box_feat)                                   # :743
+                rois_d = torch.from_numpy(np.asarray(rpn_ret['rois'], np.float32)).to(dev)
+                score_thresh, iter_num = cfg.TEST_SCORE_THRESH, 0
+                while score_thresh >= -1e-05:                                                    # :911-935
+                    d_rois, d_lab, d_sc, _ = box_ops.prepare_det_rois(
+                        rois_d, cls_score, bbox_pred, im_info_np, score_thresh, cfg.TEST_NMS, cfg.DETECTIONS_PER_IM, 1)
+                    if d_rois.shape[0] > 0:
+                        break
+                    if score_thresh >= 0.02 - 1e-04:
+                        score_thresh -= 0.01
+                    elif iter_num <= 50:
+                        score_thresh /= 2.0
+                        iter_num += 1
+                    else:
+                        score_thresh = -2e-06
+                det_rois = d_rois.cpu().numpy().astype(np.float32)
+                det_labels = [d_lab.cpu().numpy().astype(np.int64)]
+                det_scores = [d_sc.cpu().numpy().astype(np.float32)]
+            outs = self.forward_clips(all_frames, blob_conv, feat_map, [det_rois], im_scale=im_scale, f_scale=f_scale,
+                                      det_labels=det_labels, det_scores=det_scores, pairs=pairs, pair_labels=pair_labels)
+            if outs is None:                        # overlap_steps returns the previous step: one clip per call wants its own
+                outs = self.flush_steps()
+            o = outs[0]
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+            ret = {}
+            ret['sbj_rois'], ret['obj_rois'] = t(o['sbj_rois']), t(o['obj_rois'])
+            ret['sbj_labels'] = o['sbj_labels'].to(torch.int32).cpu()                            # 1-based (:873-874)
+            ret['obj_labels'] = o['obj_labels'].to(torch.int32).cpu()
+            ret['sbj_scores'], ret['obj_scores'] = o['sbj_scores'].float().cpu(), o['obj_scores'].float().cpu()
+            ret['det_rois'] = t(o['det_rois'])
+            ret['det_labels'] = o['det_labels'].to(torch.int32).cpu()
+            ret['msp_det_scores'] = o['msp_det_scores']
+            ret['sbj_inds'], ret['obj_inds'] = t(np.asarray(o['sbj_inds']).reshape(-1)), t(np.asarray(o['obj_inds']).reshape(-1))
+            ret['prd_scores'] = o['prd_scores']
+            if cfg.USE_FREQ_BIAS:                                                                # :1064, :1085-1086, :1178
+                lab = torch.stack((o['sbj_labels'].long() - 1, o['obj_labels'].long() - 1), 1)
+                bias = self.freq_bias.rel_index_with_labels(lab)
+                ret['prd_scores_bias'] = torch.sigmoid(bias) if cfg.MULTI_RELATION else F.softmax(bias, dim=1)
+            ret['prd_ttl_scores'] = o['prd_scores']                                              # ADD_SCORES_ALL (:1181-1182)
+            if do_vis:
+                ret['blob_conv'], ret['feat_map'] = blob_conv, feat_map
+                ret['temporal_blob_conv_prd'] = self._debug["tmaps"].permute(0, 1, 4, 2, 3).float()
+            ret['pre_processed_frames_rpn_ret'] = None                                           # :1195-1196
+            ret['pre_processed_temporal_roi'] = None
+            return ret
 
     # ------------------------------------------------------------------ whole-step HIP graph
     def _replay_step(self, all_frames, blob_conv, feat_map, prep, topk, prd_k):
@@ -621,7 +714,8 @@ class Generalized_RCNN(nn.Module):
             return x.contiguous()
         return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
-    def _host_prep(self, det_rois, Tn, im_scale, f_scale, det_labels=None, det_scores=None):
+    def _host_prep(self, det_rois, Tn, im_scale, f_scale, det_labels=None, det_scores=None, pairs_in=None,
+                   pair_labels=None):
         """Host side of a step: roi lists, box trees, pair lists (numpy, as in the reference), packed for
         one upload.  `sig` identifies every launch shape of the step."""
         cfg = self.cfg
@@ -636,7 +730,9 @@ class Generalized_RCNN(nn.Module):
         if (det_labels is None) != (det_scores is None):
             raise ValueError("det_labels and det_scores come together")
         person_sbj = det_labels is not None and cfg.dataset.find("ag") >= 0
-        if B > 1 and len(set(n_list)) == 1 and not cfg.USE_OVLP_FILTER and det_labels is None:
+        if pair_labels is not None and pairs_in is None:
+            raise ValueError("pair_labels come with explicit pairs")
+        if B > 1 and len(set(n_list)) == 1 and not cfg.USE_OVLP_FILTER and det_labels is None and pairs_in is None:
             return self._host_prep_same_n(det_all, B, n_list[0], Tn, scale3d, off)
         trees, t_obj, t_reg, reg_rois, pairs = [], [], [], [], []
         m_list = []
@@ -655,7 +751,12 @@ class Generalized_RCNN(nn.Module):
             # frame; the list keeps the reference's object-major-vs-frame-major pairing (same quirk as objects)
             t_reg.append(self._temporal_roi_list(tree["boxes"][n:].astype(np.float32), Tn, b * Tn))
             reg_rois.append(np.concatenate([np.full((m, 1), b, np.float32), tree["boxes"][n:].astype(np.float32)], 1))
-            if person_sbj or cfg.USE_OVLP_FILTER:
+            if pairs_in is not None:                                             # gt-box branch: pairs as annotated (:809-810)
+                s = np.asarray(pairs_in[b][0], np.int64).reshape(-1)
+                o = np.asarray(pairs_in[b][1], np.int64).reshape(-1)
+                if len(s) != len(o) or len(s) == 0 or s.min() < 0 or o.min() < 0 or max(s.max(), o.max()) >= n:
+                    raise ValueError("pairs[%d]: need equally long, non-empty index lists into the clip's %d rois" % (b, n))
+            elif person_sbj or cfg.USE_OVLP_FILTER:
                 # RelPN (relpn_heads.py:71-105): person subjects on Action Genome, then the overlap filter on the
                 # boxes in original image scale
                 s, o = box_ops.relpn_pair_indices(n, det_labels[b] if person_sbj else None, cfg.dataset)
@@ -701,9 +802,19 @@ class Generalized_RCNN(nn.Module):
             if lab.shape[0] != Ntot or sc.shape[0] != Ntot:
                 raise ValueError("det_labels / det_scores must hold one entry per roi")
             ix["lab"], ix["sc"] = upl.add(lab), upl.add(sc)
+        if pair_labels is not None:
+            Ptot = int(poff[-1])
+            cat = lambda k, dt: np.concatenate([np.asarray(d[k]).reshape(-1) for d in pair_labels]).astype(dt)
+            pl = dict(plab_s=cat("sbj_labels", np.int64), plab_o=cat("obj_labels", np.int64),
+                      psc_s=cat("sbj_scores", np.float32), psc_o=cat("obj_scores", np.float32))
+            if any(v.shape[0] != Ptot for v in pl.values()):
+                raise ValueError("pair_labels must hold one entry per pair")
+            for k, v in pl.items():
+                ix[k] = upl.add(v)
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list), tuple(len(p[0]) for p in pairs), det_labels is not None),
+                    sig=(Tn, tuple(n_list), tuple(m_list), tuple(len(p[0]) for p in pairs), det_labels is not None,
+                         pair_labels is not None),
                     max_tree_nodes=max(n + m for n, m in zip(n_list, m_list)))
 
     def _host_prep_same_n(self, det_all, B, n, Tn, scale3d, off):
@@ -767,7 +878,7 @@ class Generalized_RCNN(nn.Module):
         n_list = [n] * B
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=B * n, Mtot=B * m,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False), max_tree_nodes=n + m)
+                    sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False, False), max_tree_nodes=n + m)
 
     def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone, phase="all", hand=None):
         """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
@@ -850,7 +961,8 @@ class Generalized_RCNN(nn.Module):
                         b = torch.cat([bv, wa @ bv, wb @ bv], 0).contiguous()
                         bab = (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous()
                         return w, b, bab
-                    w_vab, b_vab, bias_ab = self._cached("vab", make_vab)
+                    w_vab, b_vab, bias_ab = self._cached("vab", make_vab, self._layer_deps(
+                        [self.spatio_atten_map, self.spatio_inferA[0], self.spatio_inferB[0]]))
                     vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
                     vmap = None
                     # with the second stream the union-box pooling (the heavy half of the pair kernel) runs here,
@@ -867,8 +979,10 @@ class Generalized_RCNN(nn.Module):
                 w_sm, b_sm, n_rel = self._stack_w("sem_so", [self.sem_s[0], self.sem_o[0]])
                 parts = ops.gemm_nt(det_so_bf, w_sm, bias=b_sm, out_f32=True)            # (2, Ntot, n_rel padded)
                 freq = self.freq_bias.rel_baseline.weight.detach() if cfg.USE_FREQ_BIAS else None    # :1064,:1075
+                per_pair = tuple(dv[ix[k]] for k in ("plab_s", "plab_o", "psc_s", "psc_o")) if "plab_s" in ix else None
                 sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all, so_bias, so_part = ops.pair_assemble(
-                    det_labels, det_scores, X, Y, lows[0], lows[1], parts[0], parts[1], freq, n_rel, cfg.NUM_CLASSES - 1)
+                    det_labels, det_scores, X, Y, lows[0], lows[1], parts[0], parts[1], freq, n_rel, cfg.NUM_CLASSES - 1,
+                    per_pair=per_pair)
                 pa.update(det_labels=det_labels, det_scores=det_scores, det_feat=det_feat, det_feat_bf=det_feat_bf,
                           reg_feat=reg_feat, reg_feat_bf=reg_feat_bf, kmap=kmap, vmap=vmap,
                           vab=vab if self.fuse_pair_infer else None, bias_ab=bias_ab if self.fuse_pair_infer else None,
@@ -990,7 +1104,8 @@ class Generalized_RCNN(nn.Module):
             wab, bab, _ = self._cached("inferAB", lambda: (
                 torch.cat([self.spatio_inferA[0].weight.detach().float().view(low, low),
                            self.spatio_inferB[0].weight.detach().float().view(low, low)], 1).to(torch.bfloat16).contiguous(),
-                (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low))
+                (self.spatio_inferA[0].bias.detach().float() + self.spatio_inferB[0].bias.detach().float()).contiguous(), low),
+                self._layer_deps([self.spatio_inferA[0], self.spatio_inferB[0]]))
             sp = ops.gemm_nt(so, wab, bias=bab, leaky=True, residual=v_map.view(P * ps * ps, low), residual_post=True)  # :1039-1040
         spatio_infer = self._gemm(sp.view(P, ps * ps * low), "sp_fc", [self.spatio_infer_fc[0]], (low, ps * ps), leaky=True)  # :1042 (+ leaky of :329)
         # ---- semantic branch (:1643-1668) and the sum of the four logit terms (:1066-1069, + freq bias :1075):

@@ -752,10 +752,11 @@ def gather_add_act(a, b, idx, act=None):
     return out
 
 
-def pair_assemble(det_labels, det_scores, X, Y, low_s, low_o, part_s, part_o, freq, n_rel, n_obj):
+def pair_assemble(det_labels, det_scores, X, Y, low_s, low_o, part_s, part_o, freq, n_rel, n_obj, per_pair=None):
     """Per-pair gathers (relpn_heads.py:113-116, model_builder_rel.py:1064-1075, 1662): returns sbj_lab, obj_lab
     (P) int64, sbj_sc, obj_sc (P) f32, so_bias = low_s[X]+low_o[Y] (P,wl) f32, so_part = part_s[X]+part_o[Y]
-    (+ freq[(ls-1)*n_obj + lo-1]) (P,wp) f32."""
+    (+ freq[(ls-1)*n_obj + lo-1]) (P,wp) f32.  per_pair = (sbj_lab, obj_lab int64, sbj_sc, obj_sc f32), one entry per
+    pair: labels / scores given per pair (`use_gt_labels`, model_builder_rel.py:844-858) instead of gathered per roi."""
     det_scores, low_s, low_o, part_s, part_o = _f32(det_scores), _f32(low_s), _f32(low_o), _f32(part_s), _f32(part_o)
     L.require_gpu(det_labels, X, Y)
     if det_labels.dtype != torch.int64 or X.dtype != torch.int64 or Y.dtype != torch.int64:
@@ -773,10 +774,18 @@ def pair_assemble(det_labels, det_scores, X, Y, low_s, low_o, part_s, part_o, fr
     os_ = torch.empty((P,), dtype=torch.float32, device=dev)
     so_bias = torch.empty((P, wl), dtype=torch.float32, device=dev)
     so_part = torch.empty((P, wp), dtype=torch.float32, device=dev)
+    pp = [None] * 4
+    if per_pair is not None:
+        L.require_gpu(*per_pair)
+        if (per_pair[0].dtype != torch.int64 or per_pair[1].dtype != torch.int64 or per_pair[2].dtype != torch.float32 or
+                per_pair[3].dtype != torch.float32 or any(t.numel() != P for t in per_pair)):
+            raise RuntimeError("pair_assemble: per_pair = (int64, int64, f32, f32), one entry per pair")
+        pp = [t.contiguous() for t in per_pair]
     with torch.cuda.device(dev):
-        L.check(L.lib().trace_pair_assemble(L.ptr(det_labels.contiguous()), L.ptr(det_scores), L.ptr(X.contiguous()),
-                                            L.ptr(Y.contiguous()), P, L.ptr(low_s), L.ptr(low_o), wl, L.ptr(part_s),
-                                            L.ptr(part_o), wp, L.ptr(freq), int(n_rel), int(n_obj), L.ptr(sl), L.ptr(ol),
-                                            L.ptr(ss), L.ptr(os_), L.ptr(so_bias), L.ptr(so_part), L.stream()),
+        L.check(L.lib().trace_pair_assemble_ex(L.ptr(det_labels.contiguous()), L.ptr(det_scores), L.ptr(X.contiguous()),
+                                               L.ptr(Y.contiguous()), P, L.ptr(pp[0]), L.ptr(pp[1]), L.ptr(pp[2]), L.ptr(pp[3]),
+                                               L.ptr(low_s), L.ptr(low_o), wl, L.ptr(part_s),
+                                               L.ptr(part_o), wp, L.ptr(freq), int(n_rel), int(n_obj), L.ptr(sl), L.ptr(ol),
+                                               L.ptr(ss), L.ptr(os_), L.ptr(so_bias), L.ptr(so_part), L.stream()),
                 "pair_assemble")
     return sl, ol, ss, os_, so_bias, so_part
