@@ -2,7 +2,7 @@
 """Headline benchmark: clips/sec of TRACE's per-clip relation hot path (I3D-R50 backbone ->
 ROIAlign -> context aggregation + relation scoring) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one pass of the hot path over one batch of synthetic clips per GPU: the workload
@@ -76,11 +76,29 @@ def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
                        % (done, frames.shape[1], rois[0].shape[0]))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, torch.distributed.run on
+    127.0.0.1) as CHILDREN of this process - which has not touched the GPU - and exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report a "
+                         "number for the wrong GPU count" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -91,6 +109,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
+        seen = torch.ones((1,), device=dev)
+        dist.all_reduce(seen)                      # RCCL itself must see every rank
+        if int(seen.item()) != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus says %d" % (int(seen.item()), args.gpus))
 
     from trace_amd import ops
     from trace_amd.model_builder_rel import Generalized_RCNN
