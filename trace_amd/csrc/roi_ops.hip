@@ -475,6 +475,292 @@ __global__ __launch_bounds__(64) void roi_align_fwd_sep7_nhwc_bf16_kernel(
       *reinterpret_cast<uint32_t*>(dst + (long long)(a * P + b) * C) = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
 }
 
+
+// ---------------------------------------------------------------------------
+// Forward, channels-last bf16, MATRIX form (the default for C % 128 == 0 and <= 64 bins).
+// A bin is a Cartesian product of y samples and x samples, and a sample is dropped iff its y OR its x is out of
+// range (ROIAlign_cuda.cu:22-31), so a roi's pooled map is a small matrix product over the pixels its samples touch:
+//     out[bin][ch] = sum_p Wt[bin][p] * map[p][ch],     Wt[bin][(y, x)] = wy[bin_y][y] * wx[bin_x][x].
+// One workgroup = one roi x 128 channels:
+//   * the roi's pixel box (<= 96 pixels x 256 B) goes to LDS with 16-byte loads, once;
+//   * one lane per bin derives the (at most 3 x 3) non-zero weights of its row in registers and scatters them into a
+//     zeroed [64 bins][96 pixels] image, split into bf16 hi + lo parts (w = hi + lo to 2^-17: the MFMA takes bf16
+//     operands and the weights are not bf16 numbers);
+//   * v_mfma_f32_16x16x32_bf16 with M = channels (the A operand is the pixel image read TRANSPOSED with
+//     ds_read_b64_tr_b16, rows XOR-swizzled so those reads are conflict-free), N = bins, K = pixels, f32 accumulators;
+//   * the accumulators go through LDS once more so that every store is 16 bytes per lane and a bin row of the
+//     workgroup is 256 contiguous bytes.
+// The VALU forms this replaces were instruction-bound, not memory-bound: 9 pixels x 8 channels of unpack + FMA per
+// lane and bin is 0.7 G lane-instructions per call (17 us of the chip's 64 lanes/clk/CU) for 38 MB of traffic.
+// Covers sampling grids <= 2 x 2 with bins <= 2 pixels whose box fits (sampling_ratio 1-2, and adaptive grids of rois
+// up to 14 pixels: every roi of a 14 x 14 map); other rois take the generic sample walk with loads straight from L2.
+// f32 accumulation in a different order than the f32 NCHW kernel (feature-path tolerance; the bit-exact contract is
+// the f32 kernel's).
+// ---------------------------------------------------------------------------
+constexpr int RM_MAXPIX = 96;     // staged pixels (K of the product): 96 x 256 B = 24 KiB
+constexpr int RM_MAXBINS = 64;    // N of the product
+constexpr int RM_WSTRIDE = 208;   // bytes per weight-image row: 96 bf16 + 16 (13 chunks: 16 rows hit 16 different chunks mod 16)
+constexpr int RM_OSTRIDE = 272;   // bytes per output-image row: 128 bf16 + 16
+constexpr int RM_THREADS = 256;   // 4 waves: 2 (channels) x 2 (bins)
+
+typedef __attribute__((ext_vector_type(4))) short rm_s4;
+typedef __attribute__((ext_vector_type(8))) short rm_s8;
+typedef __attribute__((ext_vector_type(4))) float rm_f4;
+
+// byte offset of 16-byte chunk `ch` (0..15) of pixel row `row` (cdna_hip_programming.md T10, image (b))
+__device__ __forceinline__ int rm_poff(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// The (at most three) consecutive pixels the one or two samples of a bin touch along one axis, with their summed
+// weights (x 1 / grid): first = lo of sample 0; valid for grid <= 2 and sample spacing <= 1 pixel.
+struct Axis3 {
+  int first;
+  float w[3];
+};
+// sample_coord for grid 1 or 2: x / grid == x * inv exactly (inv = 1 or 0.5), without the IEEE division sequence
+__device__ __forceinline__ float sample_coord12(float start, int p, float bin, int i, float inv) {
+  return start + (float)p * bin + (((float)i + .5f) * bin) * inv;
+}
+__device__ __forceinline__ Axis3 axis3(float start, int b, float bsz, int grid, int dim) {
+  const float inv = grid == 2 ? 0.5f : 1.0f;
+  const Lin1 s0 = lin_setup(sample_coord12(start, b, bsz, 0, inv), dim);
+  const Lin1 s1 = lin_setup(sample_coord12(start, b, bsz, grid - 1, inv), dim);   // grid 1: the same sample again
+  const float l0 = s0.valid ? s0.wl * inv : 0.f, h0 = s0.valid ? s0.wh * inv : 0.f;
+  const bool two = grid > 1;
+  const float l1 = (two && s1.valid) ? s1.wl * inv : 0.f, h1 = (two && s1.valid) ? s1.wh * inv : 0.f;
+  const int d = s1.lo - s0.lo;   // 0 or 1 (2 only by float rounding of a spacing of exactly one pixel: then wh of sample 1 is ~0)
+  Axis3 r;
+  r.first = s0.lo;
+  // sample 0: wl on first, wh on first + 1 (clamped at the border: hi == lo and wh == 0)
+  // sample 1: wl on first + d, wh on first + d + 1
+  r.w[0] = l0 + (d == 0 ? l1 : 0.f);
+  r.w[1] = h0 + (d == 0 ? h1 : 0.f) + (d == 1 ? l1 : 0.f);
+  r.w[2] = (d == 1 ? h1 : 0.f) + (d >= 2 ? l1 + h1 : 0.f);
+  return r;
+}
+
+__global__ __launch_bounds__(RM_THREADS, 3) void roi_align_fwd_mfma_nhwc_bf16_kernel(
+    const uint16_t* __restrict__ in, int B, int H, int W, int C, const float* __restrict__ rois, float scale, int PH,
+    int PW, int sr, int slabs, uint16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) unsigned char pimg[RM_MAXPIX * 256];            // pixels; later the output tile
+  __shared__ __attribute__((aligned(16))) unsigned char wimg[2 * RM_MAXBINS * RM_WSTRIDE];  // weights: hi image, lo image
+  // Workgroups go to the 8 XCDs round-robin by linear id and each XCD has its own L2: give XCD x the x-th contiguous
+  // eighth of the (roi, slab group) units, so that rois sorted by image (as every caller here passes them) read
+  // a map slice that stays in that XCD's L2
+  int n, sg;
+  {
+    const int total = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = lin & 7, per = total >> 3, rem = total & 7;
+    const int unit = xcd * per + min(xcd, rem) + (lin >> 3);
+    n = unit / (int)gridDim.x;
+    sg = unit - n * (int)gridDim.x;
+  }
+  const int tid = threadIdx.x;
+  const int c0 = sg * slabs * 128;   // this workgroup's `slabs` consecutive 128-channel slabs share the weight image
+  const int nbins = PH * PW;
+  const RoiGeom g = roi_geom(rois + (long long)n * 5, scale, PH, PW, sr, B);
+  const uint16_t* img = in + (long long)g.batch * H * W * C + c0;
+  uint16_t* obase = out + (long long)n * nbins * C + c0;
+  // pixel box of the first / last sample of each axis (sample coordinates are monotonic; the clamped coordinates of
+  // dropped samples only widen it); everything here is uniform over the workgroup
+  const bool small = g.grid_h <= 2 && g.grid_w <= 2 && g.bin_h <= 2.0f && g.bin_w <= 2.0f;
+  const float ivh = g.grid_h == 2 ? 0.5f : 1.0f, ivw = g.grid_w == 2 ? 0.5f : 1.0f;   // only used when `small`
+  const Lin1 fy = lin_setup(sample_coord12(g.start_h, 0, g.bin_h, 0, ivh), H);
+  const Lin1 ly = lin_setup(sample_coord12(g.start_h, PH - 1, g.bin_h, g.grid_h - 1, ivh), H);
+  const Lin1 fx = lin_setup(sample_coord12(g.start_w, 0, g.bin_w, 0, ivw), W);
+  const Lin1 lx = lin_setup(sample_coord12(g.start_w, PW - 1, g.bin_w, g.grid_w - 1, ivw), W);
+  const int y0 = fy.lo, y1 = ly.hi, x0 = fx.lo, x1 = lx.hi;
+  const int bw = x1 - x0 + 1, bh = y1 - y0 + 1, npix = bh * bw;
+  const bool fast = small && npix <= RM_MAXPIX;
+  if (!fast) {
+    // larger sample grids / bins / boxes: the sample walk of the per-bin kernel, 16 lanes x 16 bytes per bin
+    const int grp = tid >> 4, l = tid & 15;
+    const float inv_count = 1.0f / g.count;
+    for (int bs = grp; bs < nbins * slabs; bs += RM_THREADS / 16) {
+      const int sl = bs / nbins, bin = bs - sl * nbins;
+      const int a = bin / PW, b = bin - a * PW;
+      const uint16_t* simg = img + sl * 128;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float y = sample_coord(g.start_h, a, g.bin_h, iy, g.grid_h);
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const float x = sample_coord(g.start_w, b, g.bin_w, ix, g.grid_w);
+          const Bilin bl = bilin_setup(y, x, H, W);
+          if (!bl.valid) continue;
+          const int pp[4] = {bl.p1, bl.p2, bl.p3, bl.p4};
+          const float ww[4] = {bl.w1, bl.w2, bl.w3, bl.w4};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4*>(simg + (long long)pp[k] * C + l * 8);
+            const uint32_t* q = &v.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[2 * j] += ww[k] * __uint_as_float(q[j] << 16);
+              acc[2 * j + 1] += ww[k] * __uint_as_float(q[j] & 0xffff0000u);
+            }
+          }
+        }
+      }
+      uint4 o;
+      o.x = pack_bf16x2(acc[0] * inv_count, acc[1] * inv_count);
+      o.y = pack_bf16x2(acc[2] * inv_count, acc[3] * inv_count);
+      o.z = pack_bf16x2(acc[4] * inv_count, acc[5] * inv_count);
+      o.w = pack_bf16x2(acc[6] * inv_count, acc[7] * inv_count);
+      *reinterpret_cast<uint4*>(obase + (long long)bin * C + sl * 128 + l * 8) = o;
+    }
+    return;
+  }
+  const int ksteps = (npix + 31) >> 5, kpad = ksteps * 32;
+  // 1. the first slab's pixel loads in flight: 16 pixels x 16 chunks of 16 bytes per pass.  Rows npix .. kpad-1 are
+  //    zero (0 x stale NaN = NaN).  One division per lane, then pixel p + 16 by increments.
+  const int t16 = tid >> 4, tc = tid & 15;
+  uint4 px[RM_MAXPIX / 16];
+  int poff[RM_MAXPIX / 16];   // element offset of this lane's chunk of pixel p inside a slab; -1: no such pixel
+  {
+    // small-integer quotients through one v_rcp_f32: (a + .5) / bw is at least .5 / bw away from an integer
+    const float rbw = __builtin_amdgcn_rcpf((float)bw);
+    const int q16 = (int)(16.5f * rbw), r16 = 16 - q16 * bw;
+    int py = (int)(((float)t16 + .5f) * rbw), pxx = t16 - py * bw;
+#pragma unroll
+    for (int it = 0; it < RM_MAXPIX / 16; ++it) {
+      poff[it] = (t16 + 16 * it) < npix ? ((y0 + py) * W + x0 + pxx) * C + tc * 8 : -1;
+      pxx += r16;
+      py += q16;
+      if (pxx >= bw) {
+        pxx -= bw;
+        ++py;
+      }
+      px[it] = make_uint4(0, 0, 0, 0);
+      if (poff[it] >= 0) px[it] = *reinterpret_cast<const uint4*>(img + (n & (slabs - 1)) * 128 + poff[it]);
+    }
+  }
+  // 2. zero the weight images
+  for (int i = tid; i < 2 * RM_MAXBINS * RM_WSTRIDE / 16; i += RM_THREADS) reinterpret_cast<uint4*>(wimg)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  // 3. one lane per bin scatters its non-zero weights; zero-weight entries (the clamped duplicates at a border) go
+  //    to the row's pad column, which no read touches
+  if (tid < nbins) {
+    const int a = (int)(((float)tid + .5f) * __builtin_amdgcn_rcpf((float)PW)), b = tid - a * PW;
+    const Axis3 ay = axis3(g.start_h, a, g.bin_h, g.grid_h, H);
+    const Axis3 ax = axis3(g.start_w, b, g.bin_w, g.grid_w, W);
+    uint16_t* whi = reinterpret_cast<uint16_t*>(wimg + tid * RM_WSTRIDE);
+    uint16_t* wlo = reinterpret_cast<uint16_t*>(wimg + RM_MAXBINS * RM_WSTRIDE + tid * RM_WSTRIDE);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float w = ay.w[i] * ax.w[j];
+        const int yy = ay.first + i, xx = ax.first + j;
+        const int p = (w != 0.f && yy <= y1 && xx <= x1) ? (yy - y0) * bw + (xx - x0) : RM_MAXPIX;
+        const uint16_t hi = f32_to_bf16(w);
+        whi[p] = hi;
+        wlo[p] = f32_to_bf16(w - bf16_to_f32(hi));
+      }
+  }
+  // pixels -> image `dst`: rows XOR-swizzled by 16-byte chunk (rm_poff) and, on rows with bit 3 set, the two 8-byte
+  // halves of a chunk swapped, so that the two 16-lane groups of a transposed read below land on different banks
+  auto put_pixels = [&](unsigned char* dst) {
+#pragma unroll
+    for (int it = 0; it < RM_MAXPIX / 16; ++it) {
+      const int p = t16 + 16 * it;
+      if (p < kpad) {
+        const bool sw = (p >> 3) & 1;
+        uint4 v = px[it];
+        if (sw) v = make_uint4(v.z, v.w, v.x, v.y);
+        *reinterpret_cast<uint4*>(dst + rm_poff(p, tc)) = v;
+      }
+    }
+  };
+  // Slab order rotated by the roi index: the rois of one image run at the same time on one XCD, and only whoever
+  // touches a slab of the map first waits for HBM; after the first step every workgroup reads what a neighbour fetched
+  const int rot = n & (slabs - 1);   // slabs is 1, 2 or 4
+  auto slab_of = [&](int i) { return (i + rot) & (slabs - 1); };
+  auto get_pixels = [&](int i) {
+    const int so = slab_of(i) * 128;
+#pragma unroll
+    for (int it = 0; it < RM_MAXPIX / 16; ++it)
+      if (poff[it] >= 0) px[it] = *reinterpret_cast<const uint4*>(img + so + poff[it]);
+  };
+  put_pixels(pimg);
+  if (slabs > 1) get_pixels(1);
+  __syncthreads();
+  // 4. out^T[ch][bin] = map^T[ch][p] . Wt^T[p][bin] on v_mfma_f32_16x16x32_bf16.  Waves 2 x 2: wave (wm, wn) owns
+  //    channels 64 wm .. 64 wm + 63 and bins 32 wn .. 32 wn + 31.  Its weight fragments are the same for every slab and
+  //    stay in registers, after which the weight image's LDS is the second pixel buffer.
+  //    The A operand's 16 rows are the channels 32 pair + 8 (m >> 2) + 4 t + (m & 3) (tile t of a pair of M tiles): a lane
+  //    then holds, over t = 0, 1, eight consecutive channels of one bin, a 16-byte store.
+  const int lane = tid & 63, wv = tid >> 6, wm = wv & 1, wn = wv >> 1;
+  const int kg = lane >> 4, li = lane & 15, q = li >> 2, pq = li & 3;
+  rm_s8 wf[2][RM_MAXPIX / 32][2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < RM_MAXPIX / 32; ++ks) {
+      const unsigned char* wrow = wimg + (32 * wn + 16 * nt + li) * RM_WSTRIDE + (32 * ks + 8 * kg) * 2;
+      wf[nt][ks][0] = *reinterpret_cast<const rm_s8*>(wrow);
+      wf[nt][ks][1] = *reinterpret_cast<const rm_s8*>(wrow + RM_MAXBINS * RM_WSTRIDE);
+    }
+  __syncthreads();   // every wave holds its fragments: the weight image may be overwritten
+  for (int sl = 0; sl < slabs; ++sl) {
+    unsigned char* pcur = (sl & 1) ? wimg : pimg;
+    if (sl + 1 < slabs) {
+      put_pixels((sl & 1) ? pimg : wimg);   // loaded one slab ago
+      if (sl + 2 < slabs) get_pixels(sl + 2);
+    }
+    rm_f4 acc[2][2][2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[pr][t][nt] = rm_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < RM_MAXPIX / 32; ++ks) {
+      if (ks < ksteps) {
+        rm_s8 af[2][2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int row = 32 * ks + 8 * kg + q, chunk = 8 * wm + 4 * pr + pq, half = 8 * (t ^ (kg & 1));
+            const rm_s4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) rm_s4*)(pcur + rm_poff(row, chunk) + half));
+            const rm_s4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) rm_s4*)(pcur + rm_poff(row + 4, chunk) + half));
+            af[pr][t] = rm_s8{lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+          }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                acc[pr][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[pr][t], wf[nt][ks][h], acc[pr][t][nt], 0, 0, 0);
+      }
+    }
+    // accumulator rows 4 kg + r of tile t = channels 8 kg + 4 t + r of the pair; column li = bin
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int bin = 32 * wn + 16 * nt + li;
+      if (bin < nbins) {
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          uint4 o;
+          o.x = pack_bf16x2(acc[pr][0][nt][0], acc[pr][0][nt][1]);
+          o.y = pack_bf16x2(acc[pr][0][nt][2], acc[pr][0][nt][3]);
+          o.z = pack_bf16x2(acc[pr][1][nt][0], acc[pr][1][nt][1]);
+          o.w = pack_bf16x2(acc[pr][1][nt][2], acc[pr][1][nt][3]);
+          *reinterpret_cast<uint4*>(obase + (long long)bin * C + slab_of(sl) * 128 + 64 * wm + 32 * pr + 8 * kg) = o;
+        }
+      }
+    }
+    __syncthreads();   // this slab's image is read out, the next one is written
+  }
+}
+
 static int grid_for(long long n) {
   long long b = (n + 255) / 256;
   if (b > 256LL * 32) b = 256LL * 32;
@@ -563,9 +849,21 @@ extern "C" int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H
   if (K == 0 || C == 0) return 0;
   TRACE_REQUIRE(K <= 65535, "roi_align_fwd_nhwc: K=%d exceeds 65535 rois per call", K);
   TRACE_REQUIRE(input && rois && out, "roi_align_fwd_nhwc: null pointer");
-  static const bool no_sep = getenv("TRACE_ROI_NO_SEP") != nullptr;   // A/B measurements
-  // measured (160 rois x 2048 ch on 14x14 maps): sampling_ratio 2: 37.4 -> 26.6 us; adaptive grids (mostly 1x1 samples per bin
-  // at this map size) are cheaper per bin than per pixel (19.3 vs 23.5 us) and stay on the per-bin kernel
+  static const int roi_alg = getenv("TRACE_ROI_ALG") ? atoi(getenv("TRACE_ROI_ALG")) : 0;   // A/B: 1 = sep7, 2 = per-bin
+  const bool no_sep = roi_alg == 2;
+  if (roi_alg == 0 && C % 128 == 0 && pooled_h * pooled_w <= RM_MAXBINS) {
+    // a workgroup builds the roi's weight image once and walks `slabs` 128-channel slabs with it, as long as the grid
+    // still holds two workgroups per CU
+    const int nslab = C / 128;
+    int slabs = 1;
+    for (int sgl = 4; sgl > 1; sgl >>= 1)
+      if (nslab % sgl == 0 && (long long)(nslab / sgl) * K >= 512) { slabs = sgl; break; }
+    hipLaunchKernelGGL(roi_align_fwd_mfma_nhwc_bf16_kernel, dim3(nslab / slabs, K), dim3(RM_THREADS), 0, (hipStream_t)stream, input, B, H,
+                       W, C, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, slabs, out);
+    return check_launch("roi_align_fwd_mfma_nhwc_bf16");
+  }
+  // C % 128 != 0 or more than 64 bins.  Measured on the object-head call (160 rois x 2048 ch, 14 x 14 maps, graph of 20
+  // launches): per-bin 37.4 us, separable 26.6 us, matrix form above 16.6 us
   if (!no_sep && sampling_ratio >= 2 && pooled_h == 7 && pooled_w == 7 && H <= RS_MAX_DIM && W <= RS_MAX_DIM && C % 128 == 0) {
     hipLaunchKernelGGL(roi_align_fwd_sep7_nhwc_bf16_kernel, dim3(C / 128, K), dim3(64), 0, (hipStream_t)stream,
                        input, B, H, W, C, rois, spatial_scale, sampling_ratio, out);

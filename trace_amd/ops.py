@@ -167,9 +167,10 @@ def _keep(*tensors):
 class _span:
     """Brackets one igemm launch with events on the launch stream when IGEMM_TRACE is a list."""
 
-    def __init__(self, flops, nbytes=0):
+    def __init__(self, flops, nbytes=0, label=""):
         self.flops = flops
         self.nbytes = nbytes   # algorithmic bytes: every operand and the output once
+        self.label = label
 
     def __enter__(self):
         if IGEMM_TRACE is not None:
@@ -181,7 +182,7 @@ class _span:
     def __exit__(self, *a):
         if IGEMM_TRACE is not None:
             self.e.record()
-            IGEMM_TRACE.append((self.s, self.e, self.flops, self.nbytes))
+            IGEMM_TRACE.append((self.s, self.e, self.flops, self.nbytes, self.label))
         return False
 
 
@@ -236,7 +237,7 @@ def conv3d_stem_f32(x, in_ntchw, w, bias, stride_t, out_thw, relu=True):
     out = torch.empty((N, To, Ho, Wo, 64), dtype=torch.bfloat16, device=x.device)
     if bias is not None:
         bias = _f32(bias, "bias")
-    with torch.cuda.device(x.device), _span(2.0 * out.numel() * 5 * 7 * 7 * C, 4 * x.numel() + 2 * (w.numel() + out.numel())):
+    with torch.cuda.device(x.device), _span(2.0 * out.numel() * 5 * 7 * 7 * C, 4 * x.numel() + 2 * (w.numel() + out.numel()), "stem_f32 %s" % (tuple(out.shape),)):
         L.check(L.lib().trace_conv3d_stem16_f32(L.ptr(x), N, C, T, H, W, int(bool(in_ntchw)), L.ptr(w), L.ptr(bias),
                                                 int(stride_t), To, Ho, Wo, EPI_RELU if relu else 0, L.ptr(out), L.stream()),
                 "conv3d_stem_f32")
@@ -283,7 +284,9 @@ def conv3d(x, w, bias, ksize, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 
         bias = _f32(bias, "bias")
     ws = workspace(x.device)
     nbytes = 2 * (x.numel() + w.numel()) + out.numel() * out.element_size() + (2 * out.numel() if residual is not None else 0)
-    with torch.cuda.device(x.device), _span(2.0 * N * To * Ho * Wo * Cout * kt * kh * kw * Cin, nbytes):
+    with torch.cuda.device(x.device), _span(2.0 * N * To * Ho * Wo * Cout * kt * kh * kw * Cin, nbytes,
+                                            "conv k%s s%s d%s M=%d Cin=%d Cout=%d%s%s" % (tuple(ksize), tuple(stride), tuple(dilation), N * To * Ho * Wo, Cin, Cout,
+                                                                                  " +res" if residual is not None else "", " pool" if pool_t2 else "")):
         L.check(L.lib().trace_conv3d_igemm_bf16(
             L.ptr(x), N, Ti, Hi, Wi, Cin, L.ptr(w), L.ptr(bias), Cout, kt, kh, kw, stride[0], stride[1],
             stride[2], padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
@@ -376,7 +379,7 @@ def gemm_nt_dual(A, A2, B, bias=None, relu=False):
     if bias is not None:
         bias = _f32(bias, "bias")
     nbytes = 2 * (M * (K1 + K2) + N * (K1 + K2) + M * N)
-    with torch.cuda.device(A.device), _span(2.0 * M * N * (K1 + K2), nbytes):
+    with torch.cuda.device(A.device), _span(2.0 * M * N * (K1 + K2), nbytes, "gemm_dual M=%d N=%d K=%d+%d" % (M, N, K1, K2)):
         L.check(L.lib().trace_gemm_bf16_nt_dual(L.ptr(A), lda, K1, L.ptr(A2), lda2, K2, L.ptr(B), ldb, M, N, N, L.ptr(bias),
                                                 None, EPI_RELU if relu else 0, L.ptr(out), L.stream()), "gemm_bf16_nt_dual")
     return out
@@ -439,7 +442,7 @@ def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False
     ws = workspace(A.device)
     nbytes = (2 * (ba * M * K + bb * N * K) + out.numel() * out.element_size() + (2 * c2.numel() if c2 is not None else 0) +
               (residual.numel() * residual.element_size() if residual is not None else 0))
-    with torch.cuda.device(A.device), _span(2.0 * b * M * N * K, nbytes):
+    with torch.cuda.device(A.device), _span(2.0 * b * M * N * K, nbytes, "gemm b=%d M=%d N=%d K=%d%s" % (b, M, N, K, " tiled" if b_tiled else "")):
         L.check(L.lib().trace_gemm_bf16_nt_ex(L.ptr(A), L.ptr(B), M, N, K, lda, ldb, ldc, b, sA, sB, sC, float(alpha),
                                               L.ptr(bias), sBias, L.ptr(residual), epi, L.ptr(out), L.ptr(c2),
                                               _ACT[out2], L.ptr(ws), ws.numel(), L.stream()),
