@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0) with the driver contract fields plus
                  measured with events on the launch stream over the same K steps re-run launch by launch
                  right after the timed region (the timed steps replay the backbone from a HIP graph)
   cpu_baseline - the CPU oracle (a port of the reference path) timed on the host cores (rank 0, N=1)
-  roofline_roi_align - the object-head ROIAlign call of the workload against the HBM roofline
+  roofline_roi_align* / roofline_pair / roofline_nms - the bandwidth kernels of the path against the HBM roofline
 """
 import argparse
 import json
@@ -224,35 +224,15 @@ def main():
                     launches_per_step=len(trace) // args.steps, avg_launch_us=avg_ms * 1e3,
                     event_bracket_overhead_us=event_overhead_ms * 1e3,
                     gflop_per_step=sum(fl) / args.steps / 1e9)
-    # ROIAlign against the HBM roofline: the object-head pooling call of this workload (B*n rois, 2048
-    # channels, 7x7, sampling_ratio 2, channels-last bf16) timed alone with events on the current stream;
-    # algorithmic bytes = output written once + map read once + rois
-    roi_roof = None
+    # The bandwidth-bound kernels of the path against the HBM roofline, each timed alone at this
+    # workload's shapes with events around a captured graph of 20 launches (tools/bench_kernels.py): ROIAlign (object
+    # heads; adaptive grid; the fused mean variant), pair pooling / combine, NMS at the stress sizes.
+    # Algorithmic bytes = outputs written once + maps read once + rois.
+    kern = None
     if trace is not None:
-        r_all = torch.from_numpy(np.concatenate(
-            [np.concatenate([np.full((len(r), 1), i, np.float32), np.asarray(r, np.float32)[:, 1:5]], 1)
-             for i, r in enumerate(rois)], 0)).to(dev)
-        for _ in range(3):
-            ops.roi_align_nhwc(blob, r_all, 1.0 / 16, 7, 2)
-        reps = 20
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()      # 20 launches in one graph: the host's per-call cost stays out of the bracket
-        with torch.cuda.graph(g):
-            for _ in range(reps):
-                ops.roi_align_nhwc(blob, r_all, 1.0 / 16, 7, 2)
-        g.replay()
-        torch.cuda.synchronize()
-        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        g.replay()
-        e0.record()
-        torch.cuda.synchronize()
-        us = s0.elapsed_time(e0) / reps * 1e3
-        K = int(r_all.shape[0])
-        nbytes = K * 49 * blob.shape[3] * 2 + blob.numel() * 2 + K * 20
-        roi_roof = dict(bound="hbm", achieved=nbytes / us / 1e3, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=nbytes / (us * 1e-6) / HBM_PEAK, kernel="trace::roi_align_fwd_sep7_nhwc_bf16_kernel",
-                        rois=K, channels=int(blob.shape[3]), avg_launch_us=us, algorithmic_bytes_per_launch=nbytes)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_kernels
+        kern = bench_kernels.measure(dev, B=B, n=n, C=int(blob.shape[3]), fm=int(blob.shape[1]))
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, frames_c, blob_c, feat_c, rois)
@@ -265,7 +245,12 @@ def main():
                                "%d objects (%d pairs) per clip, I3D-R50-DC5 + ROIAlign + TRACE relation head; "
                                "2-D conv-body outputs synthetic" % (T, B, n, n * (n - 1)),
                    "clips_per_gpu": B, "frames": T, "objects": n, "parallelism": "clip-sharded x%d" % world},
-        "roofline": roof, "cpu_baseline": cpu, "roofline_roi_align": roi_roof,
+        "roofline": roof, "cpu_baseline": cpu,
+        "roofline_roi_align": kern and kern["roi_align"],
+        "roofline_roi_align_adaptive": kern and kern["roi_align_adaptive"],
+        "roofline_roi_align_avg": kern and kern["roi_align_avg"],
+        "roofline_pair": kern and {"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"]},
+        "roofline_nms": kern and {"rpn": kern["nms_rpn"], "per_class": kern["nms_per_class"]},
         "i3d_algorithmic_tflops": value * I3D_GFLOP_PER_CLIP / 1e3,
     }
     print(json.dumps(out))

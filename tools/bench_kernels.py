@@ -71,6 +71,35 @@ def measure(dev, B=8, n=20, Tn=4, C=2048, fm=14, seed=1):
     out["roi_align_avg"] = entry("trace::roi_align_avg_nhwc_bf16_kernel", timed(lambda: ops.roi_align_avg_nhwc(tm, trd, 1 / 16., 7, 0)),
                                  Kt * C * 2 + tm.numel() * 2 + Kt * 20, rois=Kt, channels=C,
                                  call="temporal object rois: ROIAlign + 7x7 mean, %d rois" % Kt)
+    # pair kernels (model_builder_rel.py:1524-1612 fused): union-box pooling of [V | W_A V | W_B V] and the
+    # attention-weighted combine, B * n(n-1) pairs, swapped pairs pooled once
+    from trace_amd.config import get_cfg
+    from trace_amd.model_builder_rel import swapped_pair_index
+    cfg = get_cfg()
+    D = int(cfg.LOW_FEAT_DIM)
+    X = np.concatenate([np.repeat(np.arange(n), n - 1) + b * n for b in range(B)])
+    Y = np.concatenate([np.concatenate([np.delete(np.arange(n), i) for i in range(n)]) + b * n for b in range(B)])
+    P = X.shape[0]
+    ob = rois[:, 1:]
+    un = np.concatenate([rois[X, :1], np.minimum(ob[X, :2], ob[Y, :2]), np.maximum(ob[X, 2:], ob[Y, 2:])], 1).astype(np.float32)
+    und = torch.from_numpy(un).to(dev)
+    part = torch.from_numpy(swapped_pair_index(X, Y)).to(dev)
+    Xd, Yd = torch.from_numpy(X.astype(np.int32)).to(dev), torch.from_numpy(Y.astype(np.int32)).to(dev)
+    vab = torch.randn((B, fm, fm, 3 * D), device=dev).to(torch.bfloat16)
+    qk = torch.randn((2 * B * n, B * fm * fm), device=dev)
+    bias = torch.randn((D,), device=dev)
+    uniq = int((part.cpu().numpy() < 0).sum() + (part.cpu().numpy() > np.arange(P)).sum())
+    pool_bytes = uniq * 49 * 3 * D * 2 + vab.numel() * 2 + P * 24
+    out["pair_pool"] = entry("trace::pair_pool_kernel", timed(lambda: ops.pair_pool(vab, und, 1 / 16., 7, partner=part)),
+                             pool_bytes, pairs=P, pooled_rows=uniq, D=D,
+                             call="union-box pooling of %d pairs (%d unique boxes) x 3 x %d ch" % (P, uniq, D))
+    pooled = ops.pair_pool(vab, und, 1 / 16., 7, partner=part)
+    comb_bytes = uniq * 49 * 3 * D * 2 + P * 49 * D * 2 + P * 49 * 2 * 4 * 4
+    out["pair_combine"] = entry("trace::pair_combine_kernel", timed(lambda: ops.pair_combine(pooled, (B, fm, fm), qk, und, Xd, Yd, bias, 1 / 16., 7, partner=part)),
+                                comb_bytes, pairs=P, D=D, call="softmax-weighted combine of the pooled maps -> (P,49,%d)" % D)
+    fused_bytes = P * 49 * D * 2 + vab.numel() * 2 + P * 49 * 2 * 4 * 4
+    out["pair_infer"] = entry("trace::pair_infer_kernel", timed(lambda: ops.pair_infer(vab, qk, und, Xd, Yd, bias, 1 / 16., 7, partner=part)),
+                              fused_bytes, pairs=P, D=D, call="pool + combine in one launch (no pooled map in HBM)")
     # NMS: SURVEY 8d stress sizes.  Algorithmic bytes = N*20 in + N*8 out (compute-light: boxes/s is the figure)
     N = 6000
     bx = torch.from_numpy(synth_boxes(rng, N, 3.0, 800.0)).to(dev)

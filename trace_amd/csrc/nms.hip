@@ -6,12 +6,15 @@
 // IoU tiles -> 64-bit masks, "> thresh", host-side reduce).
 //
 // MI355X design: the 64x64 tile of the CUDA kernel maps 1:1 onto one wave64
-// (lane = row box, 64-bit suppression word per lane).  The reference's D2H copy
-// + serial host loop is replaced by an on-device reduce: one wave walks the
-// sorted boxes block by block, resolves the 64 boxes of the diagonal tile with
-// register-only readlane steps, then ORs the kept rows' mask words (one word
-// column per lane, coalesced) into the running "removed" bitmap.  Everything
-// stays on the caller's stream; no host synchronisation.
+// (lane = row box, 64-bit suppression word per lane).  The sort is a rank sort
+// spread over N/64 workgroups (integer keys, no barrier-separated network).  The
+// reference's D2H copy + serial host loop is replaced by an on-device reduce:
+// one workgroup walks the sorted boxes block by block; wave 0 resolves the 64
+// boxes of the diagonal tile with one readlane step per KEPT box and carries the
+// next two columns in registers, 15 helper waves OR the kept rows' remaining
+// mask words into the "removed" bitmap in LDS two blocks behind, so no global
+// load sits on the block-to-block critical path.  Everything stays on the
+// caller's stream; no host synchronisation.
 //
 // Compiled with -ffp-contract=off: IoU is the reference's f32 expression, bit
 // for bit.
@@ -21,7 +24,7 @@
 
 namespace trace {
 
-constexpr int NMS_MAX_BOXES = 16384;  // 128 KiB of LDS for the sort; 256 mask words per row (4 per lane)
+constexpr int NMS_MAX_BOXES = 16384;  // 256 mask words per row: 4 per lane in the reduce's helper waves
 
 // trace_nms_noalloc: its scratch lives in the library's own device image (one copy per GPU, held until the process
 // ends) instead of a caller workspace.  Layout = carve(NMS_STATIC_MAX_BOXES): order 16 KiB + sorted boxes 64 KiB +
@@ -68,65 +71,64 @@ static size_t carve(int N, void* base, NmsWorkspace* ws) {
   return off;
 }
 
-// "a sorts before b": descending score, ties by ascending original index.
-__device__ __forceinline__ bool before(float sa, int ia, float sb, int ib) {
-  return (sa > sb) || (sa == sb && ia < ib);
+// Sort key: "a sorts before b" (descending score, ties by ascending original index) == key(a) > key(b).
+// -0.0f sorts with +0.0f (the float comparison of the reference treats them as equal, then the index decides).
+__device__ __forceinline__ uint64_t sort_key(float score, int index) {
+  uint32_t u = __float_as_uint(score + 0.0f);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+  return ((uint64_t)u << 32) | (uint32_t)(~index);
 }
 
-// Single-workgroup bitonic sort of (score, index) in LDS, then gather boxes.
+// Rank sort: position of box i in the sorted order = number of boxes that sort before it.  N^2 integer comparisons
+// spread over N/64 workgroups (lane = box, wave = one sixteenth of a tile of the other boxes' keys, staged in LDS
+// and read two per ds_read_b128 at a wave-uniform address) replace a single-workgroup bitonic network of 91
+// barrier-separated stages; the ranks are a permutation, so the kernel scatters boxes, areas and groups to their
+// sorted slots itself.
+constexpr int NMS_SORT_TILE = 4096;   // keys per LDS tile (32 KiB)
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes,
-                                                        const float* __restrict__ scores, int N,
-                                                        int npow2, int npad, int32_t* order,
-                                                        float4* sboxes, float* sareas,
+                                                        const float* __restrict__ scores, int N, int npad,
+                                                        int32_t* __restrict__ order, float4* __restrict__ sboxes,
+                                                        float* __restrict__ sareas,
                                                         const int32_t* __restrict__ group,
-                                                        int32_t* sgroup) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* key = (float*)smem;
-  int* idx = (int*)(smem + (size_t)npow2 * sizeof(float));
-  for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-    if (i < N) {
-      key[i] = scores[i];
-      idx[i] = i;
-    } else {
-      key[i] = -__builtin_inff();
-      idx[i] = 0x7fffffff;
+                                                        int32_t* __restrict__ sgroup) {
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[NMS_SORT_TILE];
+  __shared__ int part[16][64];
+  const int lane = threadIdx.x & 63, split = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const uint64_t ki = sort_key(i < N ? scores[i] : 0.f, i);
+  int cnt = 0;
+  for (int t0 = 0; t0 < N; t0 += NMS_SORT_TILE) {
+    const int tn = min(NMS_SORT_TILE, N - t0);
+    __syncthreads();
+    // key 0 (below every real key: real keys have the index complement in the low word) pads the tile to 32 keys per wave
+    for (int j = threadIdx.x; j < NMS_SORT_TILE; j += blockDim.x) keys[j] = j < tn ? sort_key(scores[t0 + j], t0 + j) : 0ULL;
+    __syncthreads();
+    const int per = ((tn + 15) / 16 + 1) & ~1;   // keys per wave, even
+    const int j0 = split * per, j1 = min(j0 + per, NMS_SORT_TILE);
+    for (int j = j0; j < j1; j += 2) {
+      const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(&keys[j]);
+      cnt += k2.x > ki;
+      cnt += k2.y > ki;
     }
   }
+  part[split][lane] = cnt;
   __syncthreads();
-  for (int k = 2; k <= npow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        int ixj = i ^ j;
-        if (ixj > i) {
-          float si = key[i], sj = key[ixj];
-          int ii = idx[i], ij = idx[ixj];
-          bool up = ((i & k) == 0);  // this run must end "sorted ascending position = before"
-          bool swap = up ? before(sj, ij, si, ii) : before(si, ii, sj, ij);
-          if (swap) {
-            key[i] = sj;
-            key[ixj] = si;
-            idx[i] = ij;
-            idx[ixj] = ii;
-          }
-        }
-      }
-      __syncthreads();
-    }
+  if (split == 0 && i < N) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += part[k][lane];
+    const float x1 = boxes[i * 4 + 0], y1 = boxes[i * 4 + 1], x2 = boxes[i * 4 + 2], y2 = boxes[i * 4 + 3];
+    order[r] = i;
+    sboxes[r] = make_float4(x1, y1, x2, y2);
+    sareas[r] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);  // cython_nms.pyx:44
+    sgroup[r] = group ? group[i] : 0;
   }
-  for (int i = threadIdx.x; i < npad; i += blockDim.x) {
-    if (i < N) {
-      int o = idx[i];
-      order[i] = o;
-      float x1 = boxes[o * 4 + 0], y1 = boxes[o * 4 + 1], x2 = boxes[o * 4 + 2],
-            y2 = boxes[o * 4 + 3];
-      sboxes[i] = make_float4(x1, y1, x2, y2);
-      sareas[i] = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);  // cython_nms.pyx:44
-      sgroup[i] = group ? group[o] : 0;
-    } else {
-      sgroup[i] = -1;
-      order[i] = -1;
-      sboxes[i] = make_float4(0.f, 0.f, -1.f, -1.f);
-      sareas[i] = 0.f;
+  if (blockIdx.x == 0) {
+    for (int r = N + threadIdx.x; r < npad; r += blockDim.x) {
+      sgroup[r] = -1;
+      order[r] = -1;
+      sboxes[r] = make_float4(0.f, 0.f, -1.f, -1.f);
+      sareas[r] = 0.f;
     }
   }
 }
@@ -153,9 +155,12 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
   const int ag = sgroup[row];
   const int col_size = min(N - col_blk * 64, 64);
   uint64_t t = 0;
-  const int start = (row_blk == col_blk) ? lane + 1 : 0;
+  // the diagonal tile holds BOTH triangles (the predicate is symmetric): bit i < lane of row `lane` says "earlier box
+  // i suppresses me", which is what the reduce's parallel resolve reads
+  const bool diag_tile = row_blk == col_blk;
   if (row < N) {
-    for (int i = start; i < col_size; ++i) {
+    for (int i = 0; i < col_size; ++i) {
+      if (diag_tile && i == lane) continue;
       const float4 b = cb[i];
       // cython_nms.pyx:76-83
       float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
@@ -163,7 +168,11 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
       float w = fmaxf(0.0f, xx2 - xx1 + 1.0f);
       float h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
       float inter = w * h;
-      float ovr = inter / (aa + ca[i] - inter);
+      // disjoint boxes: ovr is 0 / positive = +0 and the comparison below depends on thresh alone
+      // (areas of degenerate boxes can make the union <= 0: those take the division like everything else)
+      const float uni = aa + ca[i] - inter;
+      float ovr = 0.f;
+      if (inter != 0.f || !(uni > 0.f)) ovr = inter / uni;
       bool sup = (mode == TRACE_NMS_GT) ? (ovr > thresh) : (ovr >= thresh);
       if (sup && cg[i] == ag) t |= 1ULL << i;  // boxes of different groups (classes) never interact
     }
@@ -177,51 +186,114 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// One wave: sequential greedy pass over the sorted boxes (nms.cu:105-123 moved
-// on device).  Lane l owns removed-bitmap words l, 64+l, 128+l, 192+l.
-__global__ __launch_bounds__(64) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
-                                                        const int32_t* __restrict__ order, int N,
-                                                        int col_blocks, int32_t* __restrict__ keep) {
-  const int lane = threadIdx.x;
-  uint64_t remv0 = 0, remv1 = 0, remv2 = 0, remv3 = 0;
-  for (int b = 0; b < col_blocks; ++b) {
-    const int row = b * 64 + lane;
-    const uint64_t diag = mask[(size_t)row * col_blocks + b];  // rows >= N hold 0
-    const int slot = b >> 6, owner = b & 63;
-    uint64_t mine = slot == 0 ? remv0 : slot == 1 ? remv1 : slot == 2 ? remv2 : remv3;
-    uint64_t rb = readlane64(mine, owner);
-    const int rows_here = min(N - b * 64, 64);
-    uint64_t kept = 0;
-    for (int r = 0; r < rows_here; ++r) {
-      if (!((rb >> r) & 1ULL)) {
-        kept |= 1ULL << r;
-        rb |= readlane64(diag, r);
+// Greedy pass over the sorted boxes (nms.cu:105-123 moved on device), one workgroup of 16 waves.
+// Box r of block b is kept iff no kept earlier box suppresses it, so block b needs word b of the "removed" bitmap
+// complete - but nothing else.
+//   Wave 0 walks the blocks.  The 64 boxes of the diagonal tile are resolved in parallel rounds (lane = box): a box
+//   with a kept earlier suppressor is removed, a box whose earlier suppressors are all removed is kept; the lowest
+//   undecided box always decides, and real tiles settle in a few rounds instead of 64 serial steps.  The kept lanes
+//   then OR their words for the next THREE columns (prefetched one block ahead) into the bitmap in LDS themselves.
+//   Waves 1..15 push the kept rows' remaining words (columns >= b + 4): loads issued in iteration b + 1 are OR-ed in
+//   during iteration b + 3 (two register sets, alternating), so no global load sits on the block-to-block path.
+constexpr int NMS_HELPERS = 15;
+constexpr int NMS_ROWS_PER_HELPER = 5;   // ceil(64 / 15)
+constexpr int NMS_CARRY = 3;             // columns wave 0 carries itself
+
+template <int WPL>   // mask words per lane of a helper wave: 2 up to 128 + 4 column blocks, else 4
+struct NmsPushSet {
+  uint64_t v[NMS_ROWS_PER_HELPER][WPL];
+  int base;   // first word column of v
+};
+
+template <int WPL>
+__global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
+                                                          const int32_t* __restrict__ order, int N,
+                                                          int col_blocks, int32_t* __restrict__ keep) {
+  __shared__ unsigned long long remv[NMS_MAX_BOXES / 64 + NMS_CARRY];
+  __shared__ int keptrow[2][64];   // kept rows of block it, compacted (slot it & 1); read by the helpers one iteration later
+  __shared__ int keptcnt[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < NMS_MAX_BOXES / 64 + NMS_CARRY; i += blockDim.x) remv[i] = 0ULL;
+  if (threadIdx.x < 2) keptcnt[threadIdx.x] = 0;
+  __syncthreads();
+  // wave 0: the next block's words and original indices, in flight while the current block resolves
+  uint64_t diag = 0, nx[NMS_CARRY] = {0, 0, 0};
+  int ord = -1;
+  auto wave0_fetch = [&](int b) {   // rows >= N hold 0 in every word this kernel reads (nms_mask_kernel)
+    const size_t row = (size_t)(b * 64 + lane) * col_blocks;
+    diag = mask[row + b];
+#pragma unroll
+    for (int l = 0; l < NMS_CARRY; ++l) nx[l] = b + 1 + l < col_blocks ? mask[row + b + 1 + l] : 0ULL;
+    ord = order[b * 64 + lane];
+  };
+  if (wv == 0) wave0_fetch(0);
+  NmsPushSet<WPL> setA, setB;
+#pragma unroll
+  for (int j = 0; j < NMS_ROWS_PER_HELPER; ++j)
+#pragma unroll
+    for (int k = 0; k < WPL; ++k) setA.v[j][k] = setB.v[j][k] = 0ULL;
+  setA.base = setB.base = 0;
+  // helper step: OR in what this set loaded two iterations ago, then load the kept rows of block `blk`
+  auto helper_step = [&](NmsPushSet<WPL>& st, int blk) {
+#pragma unroll
+    for (int j = 0; j < NMS_ROWS_PER_HELPER; ++j)
+#pragma unroll
+      for (int k = 0; k < WPL; ++k) {
+        if (st.v[j][k]) atomicOr(&remv[st.base + k * 64 + lane], (unsigned long long)st.v[j][k]);
+        st.v[j][k] = 0ULL;
       }
-    }
-    if (lane < rows_here) keep[order[row]] = (int)((kept >> lane) & 1ULL);
-    // OR the kept rows into the bitmap: every row of the block is loaded
-    // unconditionally (8 in flight) and masked, so the loads pipeline.
-    const size_t base = (size_t)b * 64 * col_blocks;
-    for (int r0 = 0; r0 < 64; r0 += 8) {
-      uint64_t v[8][4];
+    if (blk < 0) return;
+    const int cnt = keptcnt[blk & 1];
+    st.base = blk + 1 + NMS_CARRY;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint64_t* rowp = mask + base + (size_t)(r0 + j) * col_blocks;
+    for (int j = 0; j < NMS_ROWS_PER_HELPER; ++j) {
+      const int want = (wv - 1) + NMS_HELPERS * j;   // this wave's j-th row: the kept row of that rank
+      if (want < cnt) {
+        const int r = keptrow[blk & 1][want];
+        const uint64_t* rowp = mask + (size_t)(blk * 64 + r) * col_blocks;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int w = k * 64 + lane;
-          v[j][k] = (w > b && w < col_blocks) ? rowp[w] : 0ULL;
+        for (int k = 0; k < WPL; ++k) {
+          const int w = st.base + k * 64 + lane;
+          if (w < col_blocks) st.v[j][k] = rowp[w];
         }
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const uint64_t m = ((kept >> (r0 + j)) & 1ULL) ? ~0ULL : 0ULL;
-        remv0 |= v[j][0] & m;
-        remv1 |= v[j][1] & m;
-        remv2 |= v[j][2] & m;
-        remv3 |= v[j][3] & m;
-      }
     }
+  };
+  for (int it = 0; it < col_blocks; ++it) {
+    if (wv == 0) {
+      const uint64_t word = diag;
+      uint64_t cur[NMS_CARRY];
+#pragma unroll
+      for (int l = 0; l < NMS_CARRY; ++l) cur[l] = nx[l];
+      const int cur_ord = ord;
+      if (it + 1 < col_blocks) wave0_fetch(it + 1);
+      const int rows_here = min(N - it * 64, 64);
+      const uint64_t valid = rows_here >= 64 ? ~0ULL : ((1ULL << rows_here) - 1ULL);
+      const uint64_t in = word & ((1ULL << lane) - 1ULL);   // earlier boxes of the tile that suppress this one
+      uint64_t R = remv[it] | ~valid, K = 0;
+      for (;;) {
+        const uint64_t und = ~(R | K);
+        if (!und) break;
+        const bool mine = (und >> lane) & 1ULL;
+        const bool rm = mine && (in & K) != 0;
+        const bool kp = mine && !rm && (in & ~R) == 0;
+        K |= __ballot(kp);
+        R |= __ballot(rm);
+      }
+      if ((K >> lane) & 1ULL) {
+#pragma unroll
+        for (int l = 0; l < NMS_CARRY; ++l)
+          if (cur[l]) atomicOr(&remv[it + 1 + l], (unsigned long long)cur[l]);
+      }
+      if (lane < rows_here) keep[cur_ord] = (int)((K >> lane) & 1ULL);
+      if ((K >> lane) & 1ULL) keptrow[it & 1][__popcll(K & ((1ULL << lane) - 1ULL))] = lane;
+      if (lane == 0) keptcnt[it & 1] = __popcll(K);
+    } else {
+      if (it & 1) helper_step(setB, it - 1); else helper_step(setA, it - 1);
+    }
+    // LDS traffic of this iteration done, then a raw barrier: __syncthreads() would also wait for the global loads
+    // that are meant to stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 }
 
@@ -280,18 +352,14 @@ static int nms_launch(const float* boxes, const float* scores, const int32_t* gr
   TRACE_REQUIRE(((uintptr_t)workspace & 255) == 0, "nms: workspace must be 256-byte aligned");
   int npad = (N + 63) / 64 * 64;
   int col_blocks = npad / 64;
-  int npow2 = 64;
-  while (npow2 < N) npow2 <<= 1;
-  size_t lds = (size_t)npow2 * 8;
-  if (lds > 64 * 1024) {
-    TRACE_LDS_OPT_IN(&nms_sort_kernel, NMS_MAX_BOXES * 8, "nms");
-  }
-  hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), lds, s, boxes, scores, N, npow2, npad,
-                     ws.order, ws.sboxes, ws.sareas, group, ws.sgroup);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(col_blocks), dim3(1024), 0, s, boxes, scores, N, npad, ws.order, ws.sboxes,
+                     ws.sareas, group, ws.sgroup);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, s, ws.sboxes,
                      ws.sareas, N, col_blocks, thresh, mode, ws.sgroup, ws.mask);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(1), dim3(64), 0, s, ws.mask, ws.order, N, col_blocks,
-                     ws.keep);
+  if (col_blocks <= 128 + 1 + NMS_CARRY)
+    hipLaunchKernelGGL(nms_reduce_kernel<2>, dim3(1), dim3(1024), 0, s, ws.mask, ws.order, N, col_blocks, ws.keep);
+  else
+    hipLaunchKernelGGL(nms_reduce_kernel<4>, dim3(1), dim3(1024), 0, s, ws.mask, ws.order, N, col_blocks, ws.keep);
   hipLaunchKernelGGL(nms_compact_kernel, dim3(1), dim3(1024), 0, s, ws.keep, N, keep_out, num_keep);
   return check_launch("nms");
 }
