@@ -233,6 +233,31 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_kernels
         kern = bench_kernels.measure(dev, B=B, n=n, C=int(blob.shape[3]), fm=int(blob.shape[1]))
+    # PCIe-inclusive rate (never `value`): every step first copies its clip from pinned host memory into the resident
+    # buffer on the step's stream, un-overlapped - as the reference's f32 blob (test_engine_rel.py:420-520) and as
+    # decoded uint8 frames (trace_conv3d_stem16_u8: a quarter of the bytes)
+    pcie = None
+    if rank == 0 and not args.no_trace:
+        pcie = {}
+        model.Prd_RCNN.pixel_means = [102.9801, 115.9465, 122.7717]
+        for tag, host in (("f32", torch.empty(tuple(frames.shape), dtype=torch.float32).normal_(0, 50).pin_memory()),
+                          ("u8", torch.randint(0, 256, (B, T, 224, 224, 3), dtype=torch.uint8).pin_memory())):
+            res = torch.empty(tuple(host.shape), dtype=host.dtype, device=dev)
+            model.overlap_steps = 0
+
+            def pstep():
+                res.copy_(host, non_blocking=True)
+                return model.forward_clips(res, blob, feat, rois, topk=100, prd_k=1)
+            for _ in range(3):
+                pstep()
+            model.sync_steps()
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for _ in range(args.steps):
+                pstep()
+            model.sync_steps()
+            torch.cuda.synchronize()
+            pcie[tag] = dict(clips_per_sec=B * args.steps / (time.perf_counter() - tp0), host_bytes_per_step=host.numel() * host.element_size())
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, frames_c, blob_c, feat_c, rois)
@@ -245,7 +270,7 @@ def main():
                                "%d objects (%d pairs) per clip, I3D-R50-DC5 + ROIAlign + TRACE relation head; "
                                "2-D conv-body outputs synthetic" % (T, B, n, n * (n - 1)),
                    "clips_per_gpu": B, "frames": T, "objects": n, "parallelism": "clip-sharded x%d" % world},
-        "roofline": roof, "cpu_baseline": cpu,
+        "roofline": roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
         "roofline_roi_align": kern and kern["roi_align"],
         "roofline_roi_align_adaptive": kern and kern["roi_align_adaptive"],
         "roofline_roi_align_avg": kern and kern["roi_align_avg"],

@@ -228,6 +228,15 @@ int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, int H, int W
                             const float* bias, int st, int To, int Ho, int Wo, int epilogue, void* out,
                             trace_stream_t stream);
 
+/* The same stem from uint8 frames (N,T,H,W,C) channels-last, C <= 3, as a video decoder / cv2 leaves them:
+ * value = (float)u8 - mean[c] (`mean`: C floats in HOST memory - cfg.PIXEL_MEANS - or NULL for 0), rounded to bf16
+ * exactly as trace_conv3d_stem16_f32 rounds the f32 value, so the two entries give bit-identical outputs for the
+ * same pixels.  Replaces the f32 blob of get_frames_blob (lib/core/test_engine_rel.py:420-520: mean-subtracted f32
+ * frames, 4 bytes per sample over PCIe) when the frames are already at network resolution. */
+int trace_conv3d_stem16_u8(const uint8_t* frames, int N, int T, int H, int W, int C, const float* mean,
+                           const uint16_t* w, const float* bias, int st, int To, int Ho, int Wo, int epilogue,
+                           void* out, trace_stream_t stream);
+
 /* nn.MaxPool3d on channels-last bf16 (resnet3d.py:732-737; mmcv NonLocal3d
  * sub_sample pool).  Padding is implicit -inf as in torch. */
 int trace_maxpool3d_ndhwc_bf16(const uint16_t* in, int N, int Ti, int Hi,

@@ -82,6 +82,30 @@ def test_config1_vidvrd_batch8_32f_20_objects():
                 assert torch.equal(o[k], w[k]), k
 
 
+def test_uint8_frames_give_the_f32_clips_triplets():
+    """The harness hands over uint8-origin frames (get_frames_blob, test_engine_rel.py:420-520): decoded frames
+    (B,T,h,w,3) with Prd_RCNN.pixel_means == the f32 clip of the same mean-subtracted pixels, bit for bit, eager and
+    through the whole-step graph."""
+    from trace_amd.synthetic import make_inputs
+    m = build()
+    B, T, n = 2, 8, 10
+    _, blob, feat, rois = make_inputs(B, T, n, 224, seed=4)
+    g = torch.Generator().manual_seed(4)
+    frames_u8 = torch.randint(0, 256, (B, T, 224, 224, 3), generator=g, dtype=torch.uint8)
+    means = [102.9801, 115.9465, 122.7717]
+    clip = (frames_u8.float() - torch.tensor(means)).permute(0, 1, 4, 2, 3).contiguous()
+    m.to(DEV)
+    m.Prd_RCNN.pixel_means = means
+    ref = m.forward_clips(clip.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2)
+    ref = [{k: o[k].clone() for k in ("prd_scores", "top_pair", "top_prd", "top_scores")} for o in ref]
+    for graph in (False, True):
+        m.graph_step = graph
+        got = m.forward_clips(frames_u8.to(DEV), blob.to(DEV), feat.to(DEV), rois, topk=100, prd_k=2)
+        for o, w in zip(got, ref):
+            for k in w:
+                assert torch.equal(o[k], w[k]), (graph, k)
+
+
 def test_config2_action_genome_50_objects_overlap_filter():
     """configs[2]: AG dims (37 / 26 classes, D = 1024), n = 50 objects, USE_OVLP_FILTER, persons-only subjects."""
     from trace_amd.config import ag_config

@@ -176,3 +176,18 @@ def test_backbone_is_deterministic_at_bench_size():
         ref = ops.conv3d_stem(xp, w, b, 5, 7, 8, (4, 2, 2), (8, 112, 112), alg_k=735)
         assert torch.equal(stems[0], ref)
         del clip, stems, outs, xp, ref
+
+
+def test_backbone_takes_uint8_frames():
+    """ResNet3d.forward_ndhwc on decoded uint8 frames (N,T,H,W,C) with pixel_means == the f32 clip of the same
+    mean-subtracted pixels, bit for bit (eager and graph replay)."""
+    m = make_model(3).to(DEV)
+    m.pixel_means = [102.9801, 115.9465, 122.7717]
+    g = torch.Generator().manual_seed(9)
+    frames = torch.randint(0, 256, (1, 8, 64, 64, 3), generator=g, dtype=torch.uint8)
+    clip = (frames.float() - torch.tensor(m.pixel_means)).permute(0, 1, 4, 2, 3).contiguous()
+    ref = m.forward_ndhwc(clip.to(DEV), in_ntchw=True)
+    got = m.forward_ndhwc(frames.to(DEV))
+    assert torch.equal(got, ref)
+    got_g = m.forward_ndhwc_graphed(frames.to(DEV)).clone()
+    assert torch.equal(got_g, ref)

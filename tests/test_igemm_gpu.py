@@ -130,6 +130,35 @@ def test_conv3d_stem_matches_strided_conv():
         assert torch.equal(out3, out)
 
 
+def test_conv3d_stem_from_uint8_frames_is_bit_identical_to_the_f32_entry():
+    """trace_conv3d_stem16_u8: decoded uint8 frames (N,T,H,W,C), mean subtracted on the fly (get_frames_blob,
+    test_engine_rel.py:420-520).  Same pixels through the f32 entry -> the same bf16 outputs, bit for bit: odd
+    sizes that leave halo on every side, both temporal strides, 1- and 3-channel frames, no mean."""
+    from trace_amd import ops
+    g = torch.Generator().manual_seed(5)
+    mean3 = [102.9801, 115.9465, 122.7717]     # cfg.PIXEL_MEANS
+    for (N, T, H, W, C) in ((2, 8, 32, 32, 3), (1, 5, 64, 96, 3), (1, 4, 32, 64, 1)):
+        frames = torch.randint(0, 256, (N, T, H, W, C), generator=g, dtype=torch.uint8)
+        w = torch.randn((64, 3, 5, 7, 7), generator=g) * 0.02
+        b = torch.randn((64,), generator=g)
+        wp = torch.zeros((64, 5, 7, 8, 4))
+        wp[:, :, :, :7, :3] = w.permute(0, 2, 3, 4, 1)
+        wp = wp.reshape(64, -1).bfloat16().to(DEV)
+        for mean in (mean3[:C], None):
+            m = torch.tensor(mean if mean is not None else [0.0] * C, dtype=torch.float32)
+            clip = (frames.float() - m).permute(0, 1, 4, 2, 3).contiguous()        # (N,T,C,H,W) f32, as the reference feeds it
+            for st in (2, 4):
+                To = (T + 4 - 5) // st + 1
+                if To < 1:
+                    continue
+                Ho, Wo = H // 2, W // 2
+                ref = ops.conv3d_stem_f32(clip.to(DEV), True, wp, b.to(DEV), st, (To, Ho, Wo))
+                got = ops.conv3d_stem_u8(frames.to(DEV), mean, wp, b.to(DEV), st, (To, Ho, Wo))
+                assert torch.equal(got, ref), (N, T, H, W, C, mean is None, st, int((got != ref).sum()))
+    with pytest.raises(RuntimeError):
+        ops.conv3d_stem_u8(torch.zeros((1, 8, 32, 32, 3), dtype=torch.float32, device=DEV), None, wp, None, 2, (4, 16, 16))
+
+
 @pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024),
                                    (96, 384, 16384), (20, 64, 4096),      # split-K path
                                    (160, 384, 32768), (50, 200, 32768)])  # weight-streaming shapes

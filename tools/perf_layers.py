@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--objects", type=int, default=20)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--backbone-only", action="store_true")
+    ap.add_argument("--u8", action="store_true", help="feed decoded uint8 frames (B,T,H,W,3) instead of the f32 clip")
     args = ap.parse_args()
     from trace_amd import ops
     from trace_amd.model_builder_rel import Generalized_RCNN
@@ -33,6 +34,9 @@ def main():
     m.eval().to(dev)
     frames, blob, feat, rois = make_inputs(args.batch, args.frames, args.objects, 224, seed=1)
     frames, blob, feat = frames.to(dev), blob.to(dev), feat.to(dev)
+    if args.u8:
+        frames = torch.randint(0, 256, (args.batch, args.frames, 224, 224, 3), dtype=torch.uint8, device=dev)
+        m.Prd_RCNN.pixel_means = [102.9801, 115.9465, 122.7717]
 
     def step():
         if args.backbone_only:

@@ -58,6 +58,7 @@ SIGNATURES = {
     "trace_clip_to_ndhwc_bf16": (c_int, [P] + [c_int] * 13 + [P, P]),
     "trace_conv3d_stem_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 11 + [P, P]),
     "trace_conv3d_stem16_f32": (c_int, [P] + [c_int] * 6 + [P, P] + [c_int] * 5 + [P, P]),
+    "trace_conv3d_stem16_u8": (c_int, [P] + [c_int] * 5 + [P, P, P] + [c_int] * 5 + [P, P]),
     "trace_conv3d_igemm_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 13 + [P, c_int, P, P, c_size_t, P]),
     "trace_maxpool3d_ndhwc_bf16": (c_int, [P] + [c_int] * 14 + [P, P]),
     "trace_gemm_bf16_nt_dual": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),

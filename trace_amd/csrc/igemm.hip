@@ -68,6 +68,8 @@ struct IgemmParams {
   int pool_t2;       // 1 (dense 128x128 tiles only): the epilogue max-pools frame pairs (MaxPool3d (2,1,1)/(2,1,1)), see igemm3
   const float* in_f32;  // stem16 only: the raw f32 clip (N,C,T,H,W) or (N,T,C,H,W) instead of the padded bf16 `in`
   int f_C, f_T, f_H, f_W, f_ntchw;
+  const uint8_t* in_u8;  // stem16 only: uint8 frames (N,T,H,W,C), channels-last as decoded; value = (float)u8 - u8_mean[c]
+  float u8_mean[3];
   int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
 };
 
@@ -864,8 +866,12 @@ constexpr int ST_KSTEPS = (ST_KT * ST_KH + 1) / 2;  // 18 K-steps of two taps
 // F32IN: the patch is built from the caller's f32 clip (planar, unpadded) - converted to bf16, channel-padded to 4 and
 // written with ds_write_b128 in the same LDS image as the LDS-DMA path - so the clip never makes the round trip through
 // a padded channels-last bf16 copy (trace_clip_to_ndhwc_bf16: 154 MB read + 122 MB written per 8 clips, 73 us).
-template <bool F32IN>
+// INMODE 2: the same from uint8 frames (N,T,H,W,C) as the video decoder leaves them: (float)u8 - mean[c], rounded to bf16
+// exactly as INMODE 1 rounds the f32 value (bit-identical outputs for the same pixels), a quarter of the bytes over
+// PCIe and HBM (test_engine_rel.py:420-520 hands the network mean-subtracted f32 frames).
+template <int INMODE>
 __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
+  constexpr bool F32IN = INMODE != 0;   // the patch is built by the lanes (not LDS-DMA)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -939,15 +945,27 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
         const int t = to * p.st + f - 2, y = 2 * r0 + row - 3, x0 = 2 * c0 + 2 * ch - 3;
         const bool ok = q < ST_CHUNKS && (unsigned)t < (unsigned)T && (unsigned)y < (unsigned)H;
         const int tc = min(max(t, 0), T - 1), yc = min(max(y, 0), H - 1);
-        const float* base = p.in_f32 + (p.f_ntchw ? ((long long)n * T + tc) * C * plane : ((long long)n * C * T + tc) * plane) +
-                            (long long)yc * W;
+        if (INMODE == 1) {
+          const float* base = p.in_f32 + (p.f_ntchw ? ((long long)n * T + tc) * C * plane : ((long long)n * C * T + tc) * plane) +
+                              (long long)yc * W;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int x = x0 + e;
-          okc[r7][e] = ok && (unsigned)x < (unsigned)W;
-          const int xc = min(max(x, 0), W - 1);
+          for (int e = 0; e < 2; ++e) {
+            const int x = x0 + e;
+            okc[r7][e] = ok && (unsigned)x < (unsigned)W;
+            const int xc = min(max(x, 0), W - 1);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) raw[r7][e][c] = base[(c < C ? c : 0) * cstride + xc];
+            for (int c = 0; c < 3; ++c) raw[r7][e][c] = base[(c < C ? c : 0) * cstride + xc];
+          }
+        } else {
+          const uint8_t* base = p.in_u8 + ((((long long)n * T + tc) * H + yc) * W) * C;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int x = x0 + e;
+            okc[r7][e] = ok && (unsigned)x < (unsigned)W;
+            const int xc = min(max(x, 0), W - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) raw[r7][e][c] = (float)base[(long long)xc * C + (c < C ? c : 0)] - p.u8_mean[c];
+          }
         }
       }
 #pragma unroll
@@ -1976,10 +1994,10 @@ extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, 
   if (kt == ST_KT && kh == ST_KH && kwp == 8 && Cp == 4 && Cout == 64 && sh == 2 && sw == 2 && Ho % 16 == 0 &&
       Wo % 16 == 0 && !(epilogue & TRACE_EPI_OUT_F32) && !g_force_v2 && g_tune.tile == 0) {
     // TRACE's stem shape: LDS-resident input patch (stem16_bf16_kernel); anything else takes the generic loop
-    TRACE_LDS_OPT_IN((&stem16_bf16_kernel<false>), ST_LDS, "igemm");
+    TRACE_LDS_OPT_IN((&stem16_bf16_kernel<0>), ST_LDS, "igemm");
     const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
     TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem: grid too large");
-    hipLaunchKernelGGL(stem16_bf16_kernel<false>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(stem16_bf16_kernel<0>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
     return check_launch("conv3d_stem16");
   }
   return launch_igemm(p, 1, (hipStream_t)stream);
@@ -2018,11 +2036,51 @@ extern "C" int trace_conv3d_stem16_f32(const float* clip, int N, int C, int T, i
   p.ldo = 64;
   p.alpha = 1.0f;
   p.epi = epilogue;
-  TRACE_LDS_OPT_IN((&stem16_bf16_kernel<true>), ST_LDS, "igemm");
+  TRACE_LDS_OPT_IN((&stem16_bf16_kernel<1>), ST_LDS, "igemm");
   const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
   TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem16_f32: grid too large");
-  hipLaunchKernelGGL(stem16_bf16_kernel<true>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(stem16_bf16_kernel<1>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
   return check_launch("conv3d_stem16_f32");
+}
+
+extern "C" int trace_conv3d_stem16_u8(const uint8_t* frames, int N, int T, int H, int W, int C, const float* mean,
+                                      const uint16_t* w, const float* bias, int st, int To, int Ho, int Wo, int epilogue,
+                                      void* out, trace_stream_t stream) {
+  TRACE_REQUIRE(N >= 0 && C >= 1 && C <= 3 && T > 0 && H > 0 && W > 0 && st > 0, "conv3d_stem16_u8: bad shape");
+  TRACE_REQUIRE(Ho > 0 && Wo > 0 && To > 0 && Ho % 16 == 0 && Wo % 16 == 0, "conv3d_stem16_u8: Ho, Wo must be multiples of 16");
+  TRACE_REQUIRE(Ho == (H + 6 - 7) / 2 + 1 && Wo == (W + 6 - 7) / 2 + 1 && (To - 1) * st + 5 <= T + 4,
+                "conv3d_stem16_u8: output (%d,%d,%d) does not match a 5x7x7 / pad (2,3,3) / stride (%d,2,2) conv of (%d,%d,%d)",
+                To, Ho, Wo, st, T, H, W);
+  TRACE_REQUIRE(!(epilogue & (TRACE_EPI_OUT_F32 | TRACE_EPI_RESIDUAL)), "conv3d_stem16_u8: bf16 output, no residual");
+  long long M = (long long)N * To * Ho * Wo;
+  TRACE_REQUIRE(M < 0x7fffffffLL, "conv3d_stem16_u8: too many output positions");
+  if (M == 0) return 0;
+  TRACE_REQUIRE(frames && w && out, "conv3d_stem16_u8: null pointer");
+  TRACE_REQUIRE((((uintptr_t)w | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "conv3d_stem16_u8: pointers misaligned");
+  IgemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.in_u8 = frames;
+  for (int c = 0; c < 3; ++c) p.u8_mean[c] = (mean && c < C) ? mean[c] : 0.f;   // `mean`: C floats on the HOST (PIXEL_MEANS), or null
+  p.f_C = C; p.f_T = T; p.f_H = H; p.f_W = W;
+  p.w = w;
+  p.bias = bias;
+  p.out = out;
+  p.M = (int)M;
+  p.Cout = 64;
+  p.Crun = 32;
+  p.Ktot = ST_KT * ST_KH * 32;
+  p.To = To; p.Ho = Ho; p.Wo = Wo;
+  p.kt = ST_KT; p.kh = ST_KH; p.kw = 1;
+  p.st = st; p.sh = 2; p.sw = 2;
+  p.ldw = p.Ktot;
+  p.ldo = 64;
+  p.alpha = 1.0f;
+  p.epi = epilogue;
+  TRACE_LDS_OPT_IN((&stem16_bf16_kernel<2>), ST_LDS, "igemm");
+  const long long nwg = (long long)N * To * (Ho / 16) * (Wo / 16);
+  TRACE_REQUIRE(nwg < 0x7fffffffLL, "conv3d_stem16_u8: grid too large");
+  hipLaunchKernelGGL(stem16_bf16_kernel<2>, dim3((unsigned)nwg), dim3(256), ST_LDS, (hipStream_t)stream, p);
+  return check_launch("conv3d_stem16_u8");
 }
 
 static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda, int ldb, int ldc, int batch,

@@ -264,7 +264,8 @@ class Generalized_RCNN(PackedLinears):
     def forward_clips(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
                       det_labels=None, det_scores=None, pairs=None, pair_labels=None):
         """Inference on B clips: the batched hot path behind `forward` (which keeps the reference's one-clip signature).
-          all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688)
+          all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688); or decoded uint8 frames (B,T,h,w,3), from
+                                           which Prd_RCNN.pixel_means is subtracted inside the stem kernel
           blob_conv  (B,2048,H/16,W/16) f32 NCHW or (B,H/16,W/16,2048) bf16 — Conv_Body(data) (:702)
           feat_map   same layouts — Prd_RCNN2D(cur frame) (:1006-1007)
           det_rois   list of B numpy (n_b,5) [*,x1,y1,x2,y2] key-frame rois (:894)
@@ -493,7 +494,7 @@ class Generalized_RCNN(PackedLinears):
         into the graph's buffers (`step_buffers`), the clip and the two 2-D maps are copied in.  The
         returned tensors are the graph's output buffers: they are overwritten by the next replay."""
         dev = all_frames.device
-        key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
+        key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
                self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
         depth = max(1, int(self.pipeline))
@@ -580,7 +581,7 @@ class Generalized_RCNN(PackedLinears):
         so its tail reads a static copy that graph 1 fills after its part A; graph 1's tail reads graph 0's outputs
         in place.  Returns the per-clip dicts of step n-1 (None when nothing was pending)."""
         dev = all_frames.device
-        key = (tuple(all_frames.shape), tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
+        key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
                self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
         flushed = None

@@ -244,6 +244,35 @@ def conv3d_stem_f32(x, in_ntchw, w, bias, stride_t, out_thw, relu=True):
     return out
 
 
+def conv3d_stem_u8(x, mean, w, bias, stride_t, out_thw, relu=True):
+    """The same stem from uint8 frames x (N,T,H,W,C) channels-last (as decoded): (float)u8 - mean[c] is formed while the
+    kernel fills its LDS patch.  mean: C floats (cfg.PIXEL_MEANS) or None.  Bit-identical to `conv3d_stem_f32` on the
+    f32 clip holding the same mean-subtracted pixels."""
+    import ctypes
+    L.require_gpu(x)
+    if x.dtype != torch.uint8 or x.dim() != 5 or not x.is_contiguous():
+        raise RuntimeError("conv3d_stem_u8: frames must be a contiguous uint8 (N,T,H,W,C) tensor")
+    w = _bf16(w, "w")
+    N, T, H, W, C = x.shape
+    To, Ho, Wo = out_thw
+    if w.shape != (64, 5 * 7 * 8 * 4):
+        raise RuntimeError("conv3d_stem_u8: weight shape %s" % (tuple(w.shape),))
+    out = torch.empty((N, To, Ho, Wo, 64), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        bias = _f32(bias, "bias")
+    mean_c = None
+    if mean is not None:
+        mv = [float(v) for v in mean]
+        if len(mv) != C:
+            raise RuntimeError("conv3d_stem_u8: mean needs one value per channel")
+        mean_c = (ctypes.c_float * C)(*mv)
+    with torch.cuda.device(x.device), _span(2.0 * out.numel() * 5 * 7 * 7 * C, x.numel() + 2 * (w.numel() + out.numel()), "stem_u8 %s" % (tuple(out.shape),)):
+        L.check(L.lib().trace_conv3d_stem16_u8(L.ptr(x), N, T, H, W, C, mean_c, L.ptr(w), L.ptr(bias),
+                                               int(stride_t), To, Ho, Wo, EPI_RELU if relu else 0, L.ptr(out), L.stream()),
+                "conv3d_stem_u8")
+    return out
+
+
 def _out_size(i, k, s, p, d):
     return (i + 2 * p - d * (k - 1) - 1) // s + 1
 

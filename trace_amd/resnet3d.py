@@ -332,6 +332,7 @@ class ResNet3d(nn.Module):
 
     # -- stem ---------------------------------------------------------------
     CP = 4  # clip channels padded 3 -> 4 (8-byte pixels)
+    pixel_means = None     # per-channel means subtracted from uint8 frames (cfg.PIXEL_MEANS); None: 0
     stem_from_f32 = True   # TRACE's stem shape reads the f32 clip directly (ops.conv3d_stem_f32); False: padded bf16 copy first
 
     def _stem_weights(self):
@@ -357,7 +358,10 @@ class ResNet3d(nn.Module):
         """conv1 + BN + ReLU + maxpool (resnet3d.py:795-796).  The pool's kernel_t is 1 with
         stride_t 2, so only every second conv1 frame is ever read: the stem runs with temporal
         stride conv1_stride_t*pool1_stride_t and the pool with temporal stride 1."""
-        if in_ntchw:
+        u8 = x.dtype == torch.uint8   # decoded frames (N,T,H,W,C); `in_ntchw` does not apply
+        if u8:
+            N, T, H, W, C = x.shape
+        elif in_ntchw:
             N, T, C, H, W = x.shape
         else:
             N, C, T, H, W = x.shape
@@ -375,6 +379,13 @@ class ResNet3d(nn.Module):
         if (W + pw + pw1) % 2:
             pw1 += 1
         st = self.conv1_stride_t * self.pool1_stride_t
+        if u8:
+            if not ((kt, kh, kw) == (5, 7, 7) and kwp == 8 and self.CP == 4 and w.shape[0] == 64 and Ho % 16 == 0 and Wo % 16 == 0):
+                raise RuntimeError("uint8 frames are taken by TRACE's stem shape only (5x7x7, 64 couts, output H, W multiples "
+                                   "of 16); convert to the f32 clip for other stems")
+            # (float)u8 - pixel_means[c] while the kernel fills its LDS patch (get_frames_blob, test_engine_rel.py:420-520)
+            y = ops.conv3d_stem_u8(x, self.pixel_means, w, b, st, (To, Ho, Wo))
+            return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
         if (self.stem_from_f32 and (kt, kh, kw) == (5, 7, 7) and kwp == 8 and self.CP == 4 and w.shape[0] == 64 and
                 Ho % 16 == 0 and Wo % 16 == 0 and x.dtype == torch.float32):
             # the stem kernel converts the f32 clip while it fills its LDS patch: no padded bf16 copy of the clip
@@ -386,7 +397,8 @@ class ResNet3d(nn.Module):
         return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
     def forward_ndhwc(self, x, in_ntchw=False, stage_hook=None):
-        """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw) -> channels-last bf16 (N,T',H',W',feat_dim).
+        """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw), or uint8 decoded frames (N,T,H,W,C) from which
+        `pixel_means` is subtracted on the fly -> channels-last bf16 (N,T',H',W',feat_dim).
         stage_hook: optional (stage_index, callable): the callable runs right after residual stage `stage_index`
         (0-based; -1 = after the stem) has been launched - the relation head forks its weight-streaming branch
         onto a second stream there."""
