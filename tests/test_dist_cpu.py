@@ -64,3 +64,73 @@ def test_shard_range_matches_array_split():
             for r in range(w):
                 s, e = shard_range(n, r, w)
                 assert list(range(s, e)) == parts[r].tolist()
+
+
+def _sweep_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trace_amd.sweep import n_batches_per_rank, rank_triplets_per_video, sweep
+    n_clips, batch, topk = 11, 4, 6          # shards 6 + 5: ragged last batches, one of them shorter than the other rank's
+    calls = []
+
+    class Lagged:                             # a software-pipelined stepper: a call returns the previous batch
+        def __init__(self):
+            self.prev = None
+
+        def make(self, ids):
+            outs = []
+            for c in ids:
+                g = torch.Generator().manual_seed(1000 + c)
+                k = 1 + c % topk
+                P = 12
+                rois = np.concatenate([np.zeros((P, 1), np.float32), np.random.default_rng(c).uniform(0, 200, (P, 4)).astype(np.float32)], 1)
+                outs.append(dict(prd_scores=torch.rand((P, 5), generator=g), top_scores=torch.sort(torch.rand((k,), generator=g), descending=True)[0],
+                                 top_pair=torch.randint(0, P, (k,), generator=g), top_prd=torch.randint(0, 5, (k,), generator=g),
+                                 top_sbj=torch.randint(1, 36, (k,), generator=g), top_obj=torch.randint(1, 36, (k,), generator=g),
+                                 sbj_rois=rois, obj_rois=rois[::-1].copy()))
+            return outs
+
+        def __call__(self, ids, n_pad):
+            calls.append((list(ids), n_pad))
+            prev, self.prev = self.prev, ids
+            return None if prev is None else (prev, self.make(prev) + [None] * 3)   # trailing padding outputs are ignored
+
+        def flush(self):
+            ids, self.prev = self.prev, None
+            return ids, self.make(ids)
+
+    st = Lagged()
+    rec = sweep(st, n_clips, batch, topk, rank, world, flush_fn=st.flush)
+    nb = n_batches_per_rank(n_clips, world, batch)
+    ok = nb == 2 and rec.shape == (world * nb * batch, topk, 14)
+    ids = [int(c) for c in rec[:, 0, 12].tolist()]
+    ok = ok and sorted(c for c in ids if c >= 0) == list(range(n_clips)) and ids.count(-1) == world * nb * batch - n_clips
+    # rank 0 holds clips 0-5 (batches 4 + 2), rank 1 clips 6-10 (batches 4 + 1)
+    ok = ok and calls == ([([0, 1, 2, 3], 0), ([4, 5], 2)] if rank == 0 else [([6, 7, 8, 9], 0), ([10], 3)])
+    vids = rank_triplets_per_video(rec, clips_per_video=4, top=9)
+    ok = ok and sorted(vids) == [0, 1, 2]
+    for v, rows in vids.items():
+        ok = ok and len(rows) <= 9 and bool(np.all(np.diff(rows[:, 0]) <= 0)) and set((rows[:, 12] // 4).astype(int)) == {v}
+    # the records of a clip are the ones its owner packed
+    from trace_amd.dist import pack_triplets
+    want = pack_triplets(st.make([7]), topk, clip_offset=7)[0]
+    ok = ok and torch.equal(rec[ids.index(7)], want)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sweep_with_uneven_shards():
+    """tools/sweep.py's loop on CPU: 11 clips over 2 ranks in batches of 4 (shards of 6 and 5 clips, ragged last
+    batches), a stepper with the one-call lag of overlapped steps, one all-gather, rank-0 style per-video ranking."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert [r[1] for r in res] == [True, True]

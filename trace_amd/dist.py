@@ -37,11 +37,6 @@ def pack_triplets(outs, topk, clip_offset=0):
 
 def gather_triplets(outs, topk, clip_offset=0):
     """All ranks' records, ordered by rank: (world*B, topk, RECORD_WIDTH).  Every rank must hold the
-    same number of clips (pad the last shard with empty clips)."""
-    rec = pack_triplets(outs, topk, clip_offset)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return rec
-    world = dist.get_world_size()
-    out = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out, rec.contiguous())
-    return out
+    same number of clips (pad the last shard with empty clips: trace_amd.sweep does)."""
+    from .sweep import gather_records
+    return gather_records(pack_triplets(outs, topk, clip_offset))
