@@ -4,9 +4,9 @@ inference / pre-computed-box flow) with lib/combine_tree/cluster_tree3d.py:114-3
 
 Same sub-module names and parameter shapes as the reference (Box_Head, Box_Outs, cem_Box_Outs,
 S_Head, O_Head, Prd_RCNN, cluster_tree3d, embed_*, spatio_*, sem_*, relation_infer_*,
-freq_bias.rel_baseline) so its checkpoints load.  The two 2-D conv bodies (Conv_Body,
-Prd_RCNN2D) and the RPN are "next" rows of SURVEY.md 8(f): their outputs `blob_conv` /
-`feat_map` are inputs here.
+freq_bias.rel_baseline, Conv_Body, Prd_RCNN2D) so its checkpoints load.  `forward_clips` takes the
+2-D bodies' outputs `blob_conv` / `feat_map` as inputs (the batched entry); `forward` runs the bodies
+itself like the reference.
 
 MI355X-first differences from the reference's control flow (results are the same):
   * B clips are processed together (the reference is 1 clip per GPU call): one I3D pass, one
@@ -32,6 +32,7 @@ import torch.nn.functional as F
 from . import boxes as box_ops
 from . import cluster_tree as ct
 from . import ops
+from . import resnet2d
 from .config import TraceConfig, vidvrd_config
 from .heads import (PackedLinears, cluster_tree3d, fast_rcnn_outputs, ffn12_weights, init_msra_conv, init_xavier,
                     roi_2mlp_head, tree_gru_weights, xavier_fill)
@@ -124,7 +125,7 @@ class _Upload:
 
 
 class Generalized_RCNN(PackedLinears):
-    def __init__(self, cfg: TraceConfig = None):
+    def __init__(self, cfg: TraceConfig = None, conv_bodies=True):
         super().__init__()
         cfg = cfg or vidvrd_config()
         self.cfg = cfg
@@ -210,11 +211,13 @@ class Generalized_RCNN(PackedLinears):
         # branch, tree-GRU, query GEMMs); True: beside the backbone (measured no faster than the fused launch: 2.869 vs
         # 2.852 ms/step); False: one fused launch after the tree-GRU
         self.split_pair_pool = "tail"
-        # The three networks around the hot path stay pluggable callables: `forward` calls them exactly
-        # where the reference does.  Conv_Body(data) -> blob_conv (:702), Prd_RCNN2D(frame) -> feat_map (:1006-1007)
-        # [(1,2048,H/16,W/16) f32 NCHW or (1,H/16,W/16,2048) bf16], RPN(blob_conv, im_info, roidb) -> rpn_ret (:733).
-        self.Conv_Body = None
-        self.Prd_RCNN2D = None
+        # The networks around the hot path: `forward` calls them exactly where the reference does.
+        # Conv_Body(data) -> blob_conv (:116, :702) = ResNet101_conv5_body with res5 dilated, Prd_RCNN2D(frame) -> feat_map
+        # (:188-190, :1006-1007) = ResNet50_conv5_body_dilation2, both through the implicit-GEMM convs (resnet2d.py);
+        # conv_bodies=False leaves them out (callers of forward_clips that bring blob_conv / feat_map themselves), and
+        # any callable may be assigned instead.  RPN(blob_conv, im_info, roidb) -> rpn_ret (:733) stays pluggable.
+        self.Conv_Body = resnet2d.ResNet101_conv5_body() if conv_bodies else None
+        self.Prd_RCNN2D = resnet2d.ResNet50_conv5_body_dilation2() if conv_bodies else None
         self.RPN = None
         # a checkpoint loaded into a SUB-module (model.Box_Head.load_state_dict(..)) never reaches this class's
         # load_state_dict: every sub-module drops the packed weights (and the captured graphs, through the epoch in
@@ -261,6 +264,19 @@ class Generalized_RCNN(PackedLinears):
         return rois.reshape(-1, 5)
 
     # ------------------------------------------------------------------ forward
+    _PLUGGABLE = ("Conv_Body", "Prd_RCNN2D", "RPN")
+
+    def __setattr__(self, name, value):
+        # the networks around the hot path may be any callable (a wrapped reference module, a stub in a test), not only
+        # an nn.Module: a plain callable is kept as an ordinary attribute, outside the module tree / state dict
+        if name in self._PLUGGABLE:
+            if value is not None and not isinstance(value, nn.Module):
+                self._modules.pop(name, None)
+                object.__setattr__(self, name, value)
+                return
+            self.__dict__.pop(name, None)
+        super().__setattr__(name, value)
+
     def forward_clips(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
                       det_labels=None, det_scores=None, pairs=None, pair_labels=None):
         """Inference on B clips: the batched hot path behind `forward` (which keeps the reference's one-clip signature).

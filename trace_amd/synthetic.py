@@ -43,3 +43,28 @@ def randomize_model(model, seed=1, calib_clip=None, bn_calibrate=None):
         tab = model.freq_bias.rel_baseline.weight
         tab.data.copy_(torch.log(torch.rand(tab.shape, generator=g) * (1 - 1e-3) + 1e-3))
     return model
+
+
+def fill_resnet2d_state(module, seed=1):
+    """Seeded weights for a 2-D ResNet body (trace_amd.resnet2d or the reference's ResNet_convX_body: same key names),
+    one generator per state-dict key so that any implementation holding the same keys gets the same tensors:
+    conv ~ N(0, 2/fan_in); affine weight U(.7,1.3) (bn3 / shortcut: U(.2,.5), keeps the residual stream bounded),
+    bias, running_mean ~ N(0,.1), running_var U(.75,1.25)."""
+    import zlib
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        g = torch.Generator().manual_seed((zlib.crc32(k.encode()) + 7919 * seed) & 0x7fffffff)
+        leaf = k.rsplit(".", 1)[-1]
+        if v.dim() == 4:
+            t = torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+        elif leaf == "weight":
+            lo, hi = (0.2, 0.5) if (".bn3." in k or ".downsample." in k) else (0.7, 1.3)
+            t = torch.rand(v.shape, generator=g) * (hi - lo) + lo
+        elif leaf == "running_var":
+            t = torch.rand(v.shape, generator=g) * 0.5 + 0.75
+        else:
+            t = torch.randn(v.shape, generator=g) * 0.1
+        out[k] = t.to(v.dtype)
+    module.load_state_dict(out)
+    return module
