@@ -363,3 +363,68 @@ def prepare_det_rois(rois, scores, box_deltas, im_info, batch_size=1, score_thre
         det_scores = np.append(det_scores, s, axis=0)
         det_inds_mapping = np.append(det_inds_mapping, inds[ii], axis=0)
     return det_rois, det_labels, det_scores, det_inds_mapping
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RPN proposals
+# ---------------------------------------------------------------------------------------------------------------
+def generate_anchors(stride=16, sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1, 2)):
+    """Detectron_pytorch/lib/modeling/generate_anchors.py:48-125: (A,4) float64 anchors around a stride x stride cell,
+    aspect ratios outer, scales inner."""
+    base = float(stride)
+    scales = np.asarray(sizes, np.float64) / stride
+    ratios = np.asarray(aspect_ratios, np.float64)
+
+    def whctrs(a):
+        w, h = a[2] - a[0] + 1, a[3] - a[1] + 1
+        return w, h, a[0] + 0.5 * (w - 1), a[1] + 0.5 * (h - 1)
+
+    def mk(ws, hs, xc, yc):
+        ws, hs = ws[:, None], hs[:, None]
+        return np.hstack((xc - 0.5 * (ws - 1), yc - 0.5 * (hs - 1), xc + 0.5 * (ws - 1), yc + 0.5 * (hs - 1)))
+
+    anchor = np.array([1, 1, base, base], np.float64) - 1
+    w, h, xc, yc = whctrs(anchor)
+    ws = np.round(np.sqrt(w * h / ratios))
+    hs = np.round(ws * ratios)
+    ratio_anchors = mk(ws, hs, xc, yc)
+    out = []
+    for i in range(ratio_anchors.shape[0]):
+        w, h, xc, yc = whctrs(ratio_anchors[i])
+        out.append(mk(w * scales, h * scales, xc, yc))
+    return np.vstack(out)
+
+
+def generate_proposals(scores, bbox_deltas, im_info, anchors, feat_stride, pre_nms_topN=6000, post_nms_topN=1000,
+                       nms_thresh=0.7, min_size=0, nms_fn=None):
+    """Detectron_pytorch/lib/modeling/generate_proposals.py:62-200 for one image: scores (A,H,W), bbox_deltas (4A,H,W)
+    f32, im_info (3,) [h, w, scale].  Returns (proposals (R,4) f32, scores (R,1) f32, kept positions in the sorted
+    top-pre_nms list).  Ties in the score sort: the reference's argsort is numpy's unstable quicksort; this restatement
+    orders ties by ascending anchor index (stable), which is what the device path does.
+    nms_fn(boxes, scores, thresh) -> ascending kept indices (utils/cython_nms.pyx:37-87 semantics)."""
+    A, H, W = scores.shape
+    sx = np.arange(0, W) * feat_stride
+    sy = np.arange(0, H) * feat_stride
+    sx, sy = np.meshgrid(sx, sy, copy=False)
+    shifts = np.vstack((sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel())).transpose()
+    all_anchors = (anchors[np.newaxis, :, :] + shifts[:, np.newaxis, :]).reshape((H * W * A, 4))
+    deltas = bbox_deltas.transpose((1, 2, 0)).reshape((-1, 4))
+    sc = scores.transpose((1, 2, 0)).reshape((-1, 1))
+    order = np.argsort(-sc.squeeze(1), kind="stable")
+    if 0 < pre_nms_topN < len(sc):
+        order = order[:pre_nms_topN]
+    deltas, all_anchors, sc = deltas[order, :], all_anchors[order, :], sc[order]
+    props = clip_tiled_boxes(bbox_transform(all_anchors, deltas, (1.0, 1.0, 1.0, 1.0)), im_info[:2])
+    ms = np.float32(min_size) * np.float32(im_info[2])
+    ws = props[:, 2] - props[:, 0] + 1
+    hs = props[:, 3] - props[:, 1] + 1
+    xc = props[:, 0] + ws / 2.
+    yc = props[:, 1] + hs / 2.
+    keep = np.where((ws >= ms) & (hs >= ms) & (xc < im_info[1]) & (yc < im_info[0]))[0]
+    props, sc, pos = props[keep, :], sc[keep], keep
+    if nms_thresh > 0:
+        k = nms_fn(props, sc.squeeze(1), nms_thresh)
+        if post_nms_topN > 0:
+            k = k[:post_nms_topN]
+        props, sc, pos = props[k, :], sc[k], pos[k]
+    return props, sc, pos
