@@ -15,6 +15,8 @@
               vidvrd_utils.association at the top; dlib is absent, so an EMPTY placeholder module named dlib is
               registered (name only; nothing `evaluate` calls touches it).  The association itself
               (vidvrd_utils/association.py) needs dlib.drectangle at run time and stays unpinned.
+    ckpt_*    lib/utils_rel/net_rel.py `make_res101_map` / `make_res50_fpn_map` / `make_backbone_map` / `class_coco2ag`
+              on the model's state-dict keys, and `load_ckpt_rel` (:211-232) on a small module (tiny_*).
 """
 import json
 import os
@@ -133,11 +135,63 @@ def videos(out):
     print("videos: mAP %.4f, R@50 %.4f, P@1 %.4f" % (mean_ap, rec_at_n[50], mprec_at_n[1]))
 
 
+def ckpt_maps(out):
+    """lib/utils_rel/net_rel.py: the three name maps on every state-dict key of the model (Conv_Body, Prd_RCNN2D, RPN and
+    the heads included) plus FPN-style names, and load_ckpt_rel on a small module (same-shape copy, skipped mismatch,
+    the COCO -> AG class re-indexing branch)."""
+    import torch
+    import torch.nn as nn
+    import utils_rel.net_rel as NR
+    from trace_amd.model_builder_rel import Generalized_RCNN
+    from trace_amd.rpn import single_scale_rpn_outputs
+    m = Generalized_RCNN()
+    m.RPN = single_scale_rpn_outputs(2048, 1 / 16)
+    keys = list(m.state_dict().keys())
+    keys += ["Conv_Body.conv_top.weight", "Conv_Body.topdown_lateral_modules.1.conv_lateral.bias", "Conv_Body.posthoc_modules.2.weight",
+             "Conv_Body.conv_body.res1.conv1.weight", "Conv_Body.conv_body.res1.bn1.bias", "Conv_Body.conv_body.res3.2.conv2.weight",
+             "Conv_Body.conv_body.res4.5.bn3.running_var", "Conv_Body.conv_body.res2.0.downsample.0.weight",
+             "Conv_Body.conv_body.res2.0.downsample.1.bias", "RPN.FPN_RPN_conv.weight", "RPN.FPN_RPN_cls_score.bias",
+             "RPN.FPN_RPN_bbox_pred.weight", "Box_Head.res5.0.bn2.weight", "Box_Head.res5.1.conv3.weight",
+             "Box_Head.res5.0.downsample.0.weight", "Box_Head.res5.0.downsample.1.bias"]
+    out["ckpt_keys"] = jb(keys)
+    out["ckpt_res101"] = jb([NR.make_res101_map(k) for k in keys])
+    out["ckpt_res50fpn"] = jb([NR.make_res50_fpn_map(k) for k in keys])
+    out["ckpt_backbone"] = jb([NR.make_backbone_map(k) for k in keys])
+    c2a, idx = NR.class_coco2ag()
+    out["c2a"], out["c2a_idx"] = np.asarray(c2a, np.int64), np.asarray(idx, np.int64)
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.Box_Outs = nn.Module()
+            self.Box_Outs.cls_score = nn.Linear(8, 37)
+            self.Box_Head = nn.Module()
+            self.Box_Head.fc1 = nn.Linear(8, 4)
+            self.other = nn.Linear(3, 3)
+    t = Tiny()
+    for p in t.parameters():
+        p.data.zero_()
+    rng = np.random.default_rng(4)
+    ck = {"roi_heads.box_predictor.cls_score.weight": rng.normal(size=(81, 8)).astype(np.float32),
+          "roi_heads.box_predictor.cls_score.bias": rng.normal(size=(81,)).astype(np.float32),
+          "roi_heads.box_head.fc1.weight": rng.normal(size=(4, 8)).astype(np.float32),
+          "roi_heads.box_head.fc1.bias": rng.normal(size=(5,)).astype(np.float32),           # shape mismatch: skipped
+          "backbone.other.weight": rng.normal(size=(3, 3)).astype(np.float32)}
+    with torch.no_grad():
+        NR.load_ckpt_rel(t, ck)
+    for k, v in ck.items():
+        out["tiny_ck_" + k] = v
+    for k, v in t.state_dict().items():
+        out["tiny_sd_" + k] = v.numpy()
+    print("ckpt maps: %d keys; tiny module loaded" % len(keys))
+
+
 def main():
     cfg = ref_env.setup()
     out = {}
     frames(cfg, out)
     videos(out)
+    ckpt_maps(out)
     np.savez_compressed(os.path.join(OUT, "py_eval.npz"), **out)
     print("py_eval.npz %d bytes" % os.path.getsize(os.path.join(OUT, "py_eval.npz")))
 
