@@ -213,9 +213,11 @@ def main():
         # this same command, tools/pmc_traffic.py): bench.py cannot run under the profiler itself, so it quotes
         # the committed summary of the current round
         traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_igemm_traffic.json")
-        if os.path.exists(tp):
-            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+        for tp in ("r02_igemm_traffic.json", "r01_igemm_traffic.json"):
+            tp = os.path.join(ROOT, "profiles", tp)
+            if os.path.exists(tp):
+                traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+                break
         avg_ms = sum(ms) / len(ms)
         achieved = (sum(fl) / len(fl)) / (avg_ms * 1e-3)      # avg algorithmic FLOPs per launch / avg launch duration
         roof = dict(bound="mfma", achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
