@@ -1716,7 +1716,7 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     } else if (nblk < 256 && ksteps >= 128) {
       // deep K (weight-streaming FCs, the 12544-wide pair FC): one wave of workgroups (~2 per CU with small
       // tiles, 1 per CU with the big ones), >= 16 K-steps per slice; measured on cold operands
-      // (scratch/sweep_step.py): 21 slices for the 160 x 3072 x 100352 FC, 4 for 3040 x 256 x 12544
+      // (round-1 sweep): 21 slices for the 160 x 3072 x 100352 FC, 4 for 3040 x 256 x 12544
       const long long target = (TC + TP >= 256) ? 256 : 512;
       ks = (target + nblk / 2) / nblk;
       if (TC + TP >= 256 && p.M <= 256 && ks < 21 && ksteps >= 1024) ks = 21;
@@ -1868,7 +1868,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     else if (blocks(128, 128) >= 384) {
       // whole rounds of workgroups matter for mid-sized grids: 128x128 tiles (64 KB, 2 per CU = 512 slots) against
       // 128c x 64p (48 KB, 3 per CU = 768 slots), cost = rounds x operand bytes per K-step.  Cold sweep
-      // (scratch/sweep_dense.py): 6272 x 1536 x 1024 (588 tiles = 2 rounds of 512) 34.5 -> 29.9 us with the smaller
+      // (round-1 sweep): 6272 x 1536 x 1024 (588 tiles = 2 rounds of 512) 34.5 -> 29.9 us with the smaller
       // tile; every other backbone shape keeps 128x128 under the same rule
       tile = 4;
       const long long b4 = blocks(128, 128), b3 = blocks(128, 64);
