@@ -100,7 +100,9 @@ def nms(dets, scores, threshold, mode=NMS_GT):
     IoU > thresh (cuda/nms.cu:60) - hence the default `mode`.  NMS_GE is the
     Cython / CPU rule (>=, cython_nms.pyx:84, nms_cpu.cpp:60) that TRACE's run-time
     NMS uses; `boxes.nms` / `boxes.nms_grouped` pass it explicitly.
-    More than NMS_MAX_BOXES boxes: see `boxes.nms_large`.
+    More than NMS_MAX_BOXES (16384) boxes raise: the reduce kernel keeps its "removed" bitmap (N / 64 words) and four mask
+    words per lane in one workgroup.  TRACE's own calls stay below it (RPN: 6000 boxes before NMS; per-class NMS over the
+    score-thresholded candidates of <= 1000 proposals); cut the candidate list by score first for anything larger.
     """
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device="cpu")
