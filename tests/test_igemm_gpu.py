@@ -161,7 +161,8 @@ def test_conv3d_stem_from_uint8_frames_is_bit_identical_to_the_f32_entry():
 
 @pytest.mark.parametrize("shape", [(300, 136, 200), (3136, 256, 784), (37, 1000, 64), (1, 8, 8), (160, 1024, 1024),
                                    (96, 384, 16384), (20, 64, 4096),      # split-K path
-                                   (160, 384, 32768), (50, 200, 32768)])  # weight-streaming shapes
+                                   (160, 384, 32768), (50, 200, 32768),   # weight-streaming shapes
+                                   (150, 256, 65536), (176, 128, 65536)]) # ... on the 128c x 160p / 128c x 192p tiles
 def test_gemm_nt(shape):
     from trace_amd import ops
     M, N, K = shape
@@ -176,7 +177,8 @@ def test_gemm_nt(shape):
     _close(out2.float().cpu(), torch.relu(ref))
 
 
-@pytest.mark.parametrize("shape", [(160, 384, 32768), (50, 256, 32768), (192, 128, 65536), (300, 256, 8192)])
+@pytest.mark.parametrize("shape", [(160, 384, 32768), (50, 256, 32768), (192, 128, 65536), (300, 256, 8192),
+                                   (150, 256, 65536), (129, 128, 8192)])
 def test_gemm_nt_pretiled_weights_and_register_fed_kernel(shape):
     """Weight-streaming paths: TRACE_EPI_WTILED (ops.tile_weights layout) and the register-fed kernel (tile id 10)
     give the row-major result."""

@@ -1680,7 +1680,7 @@ static int launch_sconv9(IgemmParams& p, long long nwg, hipStream_t s) {
 // Launch configuration: tile (cout x positions), LDS ring depth, split-K factor.  0 = choose here.
 struct IgemmTune {
   int tile;    // 1: 64x64, 2: 64c x 128p, 3: 128c x 64p, 4: 128x128, 5: 128c x 256p, 6: 256c x 128p, 7: 256x256,
-               // 8: 128c x 192p, 9: 256c x 192p, 10: 64c x 64p... (see launch_igemm)
+               // 8: 128c x 192p, 9: 256c x 192p, 10: register-fed weight streaming, 12: 128c x 160p (see launch_igemm)
   int nst;     // 2..4
   int ksplit;  // >= 1
 };
@@ -1842,10 +1842,11 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
       set_error("gemm: TRACE_EPI_WTILED needs a dense problem with N %% 128 == 0 and K %% 64 == 0");
       return 1;
     }
-    if (tile != 3 && tile != 4 && tile != 8) tile = p.M <= 64 ? 3 : (p.M <= 128 || p.M > 192 ? 4 : 8);
+    if (tile != 3 && tile != 4 && tile != 8 && tile != 12) tile = p.M <= 64 ? 3 : (p.M <= 128 || p.M > 192 ? 4 : (p.M <= 160 ? 12 : 8));
     switch (tile) {
       case 3: return launch_cfg<4, 2>(p, batch, s, t.nst, t.ksplit);
       case 8: return launch_cfg<4, 6>(p, batch, s, t.nst, t.ksplit);
+      case 12: return launch_cfg<4, 5>(p, batch, s, t.nst, t.ksplit);
       default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
     }
   }
@@ -1863,7 +1864,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     const int ksteps = ceil_div(p.Ktot, BK);
     if (p.Cout <= 64) tile = 2;                                                   // 64 couts x 128 positions
     else if (p.ws && batch == 1 && p.M <= 192 && ksteps >= 1024)                  // weight streaming + split-K:
-      tile = p.M <= 64 ? 3 : (p.M <= 128 ? 4 : 8);                                //   all positions in one tile
+      tile = p.M <= 64 ? 3 : (p.M <= 128 ? 4 : (p.M <= 160 ? 12 : 8));            //   all positions in one tile
     else if (p.ws && batch == 1 && ksteps >= 128 && blocks(128, 128) <= 128) tile = 4;   // deep K: big tiles + split-K
     else if (blocks(128, 128) >= 384) {
       // whole rounds of workgroups matter for mid-sized grids: 128x128 tiles (64 KB, 2 per CU = 512 slots) against
@@ -1886,6 +1887,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     case 7: return launch_cfg<8, 8>(p, batch, s, t.nst, t.ksplit);
     case 8: return launch_cfg<4, 6>(p, batch, s, t.nst, t.ksplit);
     case 9: return launch_cfg<8, 6>(p, batch, s, t.nst, t.ksplit);
+    case 12: return launch_cfg<4, 5>(p, batch, s, t.nst, t.ksplit);
     default: return launch_cfg<4, 4>(p, batch, s, t.nst, t.ksplit);
   }
 }
@@ -1895,7 +1897,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
 using namespace trace;
 
 extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
-  TRACE_REQUIRE(tile >= 0 && tile <= 10 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
+  TRACE_REQUIRE(tile >= 0 && tile <= 12 && tile != 11 && nst >= 0 && nst <= 4 && nst != 1 && ksplit >= 0, "igemm_tune: bad configuration");
   g_tune = IgemmTune{tile, nst, ksplit};
   return 0;
 }
