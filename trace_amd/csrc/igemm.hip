@@ -1691,6 +1691,8 @@ static const bool g_force_v2 = getenv("TRACE_IGEMM_V2") != nullptr;
 static const bool g_no_tconv = getenv("TRACE_NO_TCONV") != nullptr;
 // TRACE_NO_SCONV=1 sends 1x3x3 convs through the generic loop (A/B measurements)
 static const bool g_no_sconv = getenv("TRACE_NO_SCONV") != nullptr;
+// TRACE_NO_SMALLK=1 keeps the 128 x 128 tiles for dense problems of one or two K-steps (A/B measurements)
+static const bool g_no_smallk = getenv("TRACE_NO_SMALLK") != nullptr;
 
 template <int WM, int WN>
 static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int ksplit_req) {
@@ -1866,6 +1868,12 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     else if (p.ws && batch == 1 && p.M <= 192 && ksteps >= 1024)                  // weight streaming + split-K:
       tile = p.M <= 64 ? 3 : (p.M <= 128 ? 4 : (p.M <= 160 ? 12 : 8));            //   all positions in one tile
     else if (p.ws && batch == 1 && ksteps >= 128 && blocks(128, 128) <= 128) tile = 4;   // deep K: big tiles + split-K
+    else if (!g_no_smallk && ksteps <= 2 && blocks(64, 64) >= 1024) {
+      // one or two K-steps (layer1 / layer2 conv3 at the bench batch: 200704 x 256 x 64, 25088 x 512 x 128): the launch
+      // is HBM traffic plus store bursts, and small tiles keep more workgroups' loads and stores in flight per CU -
+      // measured 53.0 -> 41.5 us (K = 64, + residual), 38.0 -> 31.1 (K = 64), 18.4 -> 16.9 (K = 128, + residual)
+      tile = ksteps == 1 ? 3 : 1;
+    }
     else if (blocks(128, 128) >= 384) {
       // whole rounds of workgroups matter for mid-sized grids: 128x128 tiles (64 KB, 2 per CU = 512 slots) against
       // 128c x 64p (48 KB, 3 per CU = 768 slots), cost = rounds x operand bytes per K-step.  Cold sweep
