@@ -88,3 +88,62 @@ def test_clip_from_frames():
     blob, s = clip_from_frames(fr2, 320)
     assert s == 320 / 240 and blob.shape == (1, 2, 3, 320, 427)
     np.testing.assert_allclose(blob[0, :, 1].numpy(), 200 - PIXEL_MEANS[1], atol=1e-4)
+
+
+def test_rel_detections_schema_round_trip_and_recall(tmp_path):
+    """test_rel.py:117-147 + test_engine_rel.py:308-352 (restated; the reference's function needs its cfg / OpenCV blob
+    path around it: parity unpinned): record keys, dtypes, label / box conventions, file names, and that the loaded
+    pickle is what `evaluation.eval_frame_recall` consumes."""
+    import pickle
+    from trace_amd import io, evaluation
+    rng = np.random.RandomState(0)
+    results = []
+    for i in range(3):
+        P = 6
+        sb = np.sort(rng.rand(P, 4).astype(np.float32) * 200, axis=1)
+        ob = np.sort(rng.rand(P, 4).astype(np.float32) * 200, axis=1)
+        rd = dict(sbj_rois=torch.from_numpy(np.hstack([np.zeros((P, 1), np.float32), sb * 1.5])),
+                  obj_rois=torch.from_numpy(np.hstack([np.zeros((P, 1), np.float32), ob * 1.5])),
+                  sbj_labels=torch.from_numpy(rng.randint(1, 36, P).astype(np.int64)),
+                  obj_labels=torch.from_numpy(rng.randint(1, 36, P).astype(np.int64)),
+                  sbj_scores=torch.from_numpy(rng.rand(P).astype(np.float32)),
+                  obj_scores=torch.from_numpy(rng.rand(P).astype(np.float32)),
+                  prd_scores=torch.from_numpy(rng.rand(P, 133).astype(np.float32)),
+                  prd_ttl_scores=torch.from_numpy(rng.rand(P, 133).astype(np.float32)))
+        det = io.det_results(rd, im_scale=1.5, add_scores_all=True)
+        assert set(det) == {"sbj_boxes", "sbj_labels", "sbj_scores", "obj_boxes", "obj_labels", "obj_scores", "prd_scores",
+                            "prd_scores_ttl"}
+        assert det["sbj_labels"].dtype == np.int32 and det["obj_labels"].dtype == np.int32
+        assert np.array_equal(det["sbj_labels"], rd["sbj_labels"].numpy() - 1)
+        np.testing.assert_allclose(det["sbj_boxes"], sb, rtol=1e-6)
+        np.testing.assert_allclose(det["obj_boxes"], ob, rtol=1e-6)
+        # ground truth = the first two predicted pairs, so recall must be 1 at any k
+        entry = dict(image="vid%d/%06d.jpg" % (i // 2, i), sbj_gt_boxes=det["sbj_boxes"][:2].copy(), obj_gt_boxes=det["obj_boxes"][:2].copy(),
+                     sbj_gt_classes=det["sbj_labels"][:2].copy(), obj_gt_classes=det["obj_labels"][:2].copy(),
+                     prd_gt_classes=np.argmax(det["prd_scores"][:2, 1:], axis=1).astype(np.int32))
+        res = io.frame_result(det, entry, do_val=True)
+        assert res["image"] == entry["image"] and set(res) - set(det) == {"image", "gt_sbj_boxes", "gt_sbj_labels", "gt_obj_boxes",
+                                                                          "gt_obj_labels", "gt_prd_labels"}
+        results.append(res)
+    assert io.det_results(dict(sbj_rois=None)) == {}
+    assert "gt_sbj_boxes" not in io.frame_result(det, entry, do_val=False)
+    assert io.det_file_name() == "rel_detections.pkl"
+    assert io.det_file_name(use_gt_boxes=True) == "rel_detections_gt_boxes_sgcls.pkl"
+    assert io.det_file_name(use_gt_boxes=True, use_gt_labels=True) == "rel_detections_gt_boxes_prdcls.pkl"
+    assert io.det_file_name(ind_range=(10, 20)) == "rel_detection_range_10_20.pkl"
+    path = io.save_detections(results, str(tmp_path), use_gt_boxes=True)
+    assert path.endswith("rel_detections_gt_boxes_sgcls.pkl")
+    back = io.load_detections(path)
+    assert len(back) == 3 and all(np.array_equal(a[k], b[k]) if isinstance(a[k], np.ndarray) else a[k] == b[k]
+                                  for a, b in zip(results, back) for k in a)
+    # a pickle that names anything but numpy's array helpers is refused
+    evil = tmp_path / "evil.pkl"
+    evil.write_bytes(pickle.dumps([os.path.join]))
+    try:
+        io.load_detections(str(evil))
+        raise AssertionError("load_detections accepted a pickle with a callable in it")
+    except pickle.UnpicklingError:
+        pass
+    # the loaded list is the evaluation's input: highest-scoring predicate of each gt pair is its gt label -> found
+    img_rec, vid_rec, top = evaluation.eval_frame_recall(back, topk=100, prd_k=1, recall_ks=(20, 50))
+    assert len(top) == 3 and 0.0 <= img_rec[20] <= 1.0 and img_rec[50] >= img_rec[20]

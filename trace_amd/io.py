@@ -7,6 +7,8 @@ Reference:
   prep_im_for_blob       Detectron_pytorch/lib/utils/blob.py:104-126, get_target_scale :141-148
   load_ckpt_rel          lib/utils_rel/net_rel.py:19-24 (class_coco2ag), :27-92 (make_res101_map), :94-147
                          (make_res50_fpn_map), :149-150 (make_backbone_map), :211-232
+  rel_detections.pkl     lib/core/test_rel.py:117-147 (per-frame result dict), lib/core/test_engine_rel.py:308-317 (image
+                         name and gt fields), :340-352 (file names per mode, one pickle of the list)
 The reference decodes and resizes with OpenCV, which this image does not have: `frame_window` / `clip_from_frames`
 take already decoded uint8 arrays from whatever decoder the caller uses, and the bilinear resize is torch's
 (align_corners=False, no antialias = cv2.INTER_LINEAR's sampling rule); pixel-level equality with cv2 is unpinned.
@@ -219,3 +221,77 @@ def load_ckpt_rel(model, ckpt):
             # initial values (measured: tests/golden/py_eval.npz tiny_sd_Box_Outs.*).  Same outcome here: not loaded.
     _PACK_EPOCH[0] += 1
     return loaded
+
+
+# ------------------------------------------------------------------------------------------ rel_detections.pkl schema
+def det_results(return_dict, im_scale=1.0, add_scores_all=False, use_freq_bias=False, use_spatial_feat=False):
+    """test_rel.py:117-147: the network's return dict -> the per-frame record the evaluation reads.  Boxes go back to
+    the original image (/ im_scale), labels become 0-based int32; `{}` when the frame produced no pair."""
+    def arr(v):
+        return v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    if return_dict.get("sbj_rois") is None:
+        return {}
+    out = dict(sbj_boxes=arr(return_dict["sbj_rois"])[:, 1:5] / im_scale,
+               sbj_labels=(arr(return_dict["sbj_labels"]) - 1).astype(np.int32, copy=False),
+               sbj_scores=arr(return_dict["sbj_scores"]),
+               obj_boxes=arr(return_dict["obj_rois"])[:, 1:5] / im_scale,
+               obj_labels=(arr(return_dict["obj_labels"]) - 1).astype(np.int32, copy=False),
+               obj_scores=arr(return_dict["obj_scores"]),
+               prd_scores=arr(return_dict["prd_scores"]))
+    if add_scores_all:
+        out["prd_scores_ttl"] = arr(return_dict["prd_ttl_scores"])
+    if use_freq_bias:
+        out["prd_scores_bias"] = arr(return_dict["prd_scores_bias"])
+    if use_spatial_feat:
+        out["prd_scores_spt"] = arr(return_dict["prd_scores_spt"])
+    return out
+
+
+def frame_result(det, entry, do_val=True):
+    """test_engine_rel.py:308-317: add the frame's name and, for validation, its ground truth (roidb entry keys)."""
+    res = dict(det)
+    res["image"] = entry["image"]
+    if do_val:
+        res.update(gt_sbj_boxes=entry["sbj_gt_boxes"], gt_sbj_labels=entry["sbj_gt_classes"],
+                   gt_obj_boxes=entry["obj_gt_boxes"], gt_obj_labels=entry["obj_gt_classes"],
+                   gt_prd_labels=entry["prd_gt_classes"])
+    return res
+
+
+def det_file_name(ind_range=None, use_gt_boxes=False, use_gt_labels=False):
+    """test_engine_rel.py:340-351."""
+    if ind_range is not None:
+        return "rel_detection_range_%s_%s.pkl" % tuple(ind_range)
+    if use_gt_boxes:
+        return "rel_detections_gt_boxes_prdcls.pkl" if use_gt_labels else "rel_detections_gt_boxes_sgcls.pkl"
+    return "rel_detections.pkl"
+
+
+def save_detections(all_results, output_dir, ind_range=None, use_gt_boxes=False, use_gt_labels=False):
+    """test_engine_rel.py:352 / utils/io.py:39-43: ONE pickle (highest protocol) of the list of per-frame dicts."""
+    import os
+    import pickle
+    path = os.path.abspath(os.path.join(output_dir, det_file_name(ind_range, use_gt_boxes, use_gt_labels)))
+    with open(path, "wb") as fh:
+        pickle.dump(list(all_results), fh, pickle.HIGHEST_PROTOCOL)
+    return path
+
+
+def load_detections(path):
+    """Read a rel_detections pickle: lists / dicts / strings / numbers / numpy arrays only - the unpickler resolves
+    numpy's array reconstruction helpers and nothing else, so a file of unknown origin cannot run code."""
+    import pickle
+
+    allowed = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+               ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+               ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+               ("numpy", "ndarray"), ("numpy", "dtype")}
+
+    class _ArraysOnly(pickle.Unpickler):
+        def find_class(self, module, name):
+            if (module, name) in allowed:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError("rel_detections: unexpected object %s.%s" % (module, name))
+
+    with open(path, "rb") as fh:
+        return _ArraysOnly(fh).load()
