@@ -281,7 +281,7 @@ int trace_gemm_bf16_nt_dual(const uint16_t* A, int lda, int K1, const uint16_t* 
 
 /* Launch-configuration override for the three entry points above, for the calling thread:
  * tile 1..9 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128, 128 x 256, 256 x 128, 256x256, 128 x 192,
- * 256 x 192), nst = LDS ring depth 2..4,
+ * 256 x 192), 10 = the register-fed weight-streaming kernel, 12 = 128 x 160; nst = LDS ring depth 2..4,
  * ksplit = split-K factor; 0 = let the library choose (the default).  No counterpart in the
  * reference (cuDNN picks its own algorithm there); used by tools/tune_igemm.py and the tests that
  * cover every tile shape. */
