@@ -1068,8 +1068,24 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const IgemmPar
   if (idx >= (long long)p.M * cq) return;
   const int m = (int)(idx / cq), c = (int)(idx % cq) * 4;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < p.ksplit; ++z) {
-    const float4 t = *reinterpret_cast<const float4*>(p.partial + ((long long)z * p.M + m) * p.Cout + c);
+  // eight slabs' loads in flight per lane; the sum keeps the slab order (bit-identical to the one-by-one loop)
+  const float* src = p.partial + (long long)m * p.Cout + c;
+  const long long zs = (long long)p.M * p.Cout;
+  int z = 0;
+  for (; z + 8 <= p.ksplit; z += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (z + u) * zs);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      v[0] += t[u].x;
+      v[1] += t[u].y;
+      v[2] += t[u].z;
+      v[3] += t[u].w;
+    }
+  }
+  for (; z < p.ksplit; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(src + z * zs);
     v[0] += t.x;
     v[1] += t.y;
     v[2] += t.z;
