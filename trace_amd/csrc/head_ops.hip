@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void pair_infer_kernel(
   // pooled [V | W_A V | W_B V] cells - 95 % of this kernel's work: the workgroup of the lower index pools once and
   // writes both pairs (each with its own softmax weights), the other one exits.
   __shared__ float sc_s[2][PA_MAX_CELLS], sc_o[2][PA_MAX_CELLS];
+  __shared__ float sm_stat[2][4];
   const int p = blockIdx.x;
   const int cells = PS * PS;
   const bool share = partner != nullptr && cells <= 64;
@@ -297,23 +298,30 @@ __global__ __launch_bounds__(256) void pair_infer_kernel(
     }
   }
   __syncthreads();
+  // softmax statistics over the cells: ONE lane per (pair, map) walks the cells in order and leaves max and 1 / sum in
+  // LDS.  (Every lane used to run all four walks for itself: 2 x 2 x cells expf per lane was a third of the kernel's
+  // vector work.)  Same order of operations, so the results are unchanged bit for bit.
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x >> 1, so = threadIdx.x & 1;
+    float mx = -__builtin_inff(), inv = 0.f;
+    if (k < npair) {
+      const float* sc = so ? sc_o[k] : sc_s[k];
+      for (int c = 0; c < cells; ++c) mx = fmaxf(mx, sc[c]);
+      float ss = 0.f;
+      for (int c = 0; c < cells; ++c) ss += expf(sc[c] - mx);
+      inv = 1.0f / ss;
+    }
+    sm_stat[k][so] = mx;
+    sm_stat[k][2 + so] = inv;
+  }
+  __syncthreads();
   float ms[2], mo[2], is[2], io[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    ms[k] = mo[k] = -__builtin_inff();
-    is[k] = io[k] = 0.f;
-    if (k >= npair) continue;
-    for (int c = 0; c < cells; ++c) {
-      ms[k] = fmaxf(ms[k], sc_s[k][c]);
-      mo[k] = fmaxf(mo[k], sc_o[k][c]);
-    }
-    float ss = 0.f, so = 0.f;
-    for (int c = 0; c < cells; ++c) {
-      ss += expf(sc_s[k][c] - ms[k]);
-      so += expf(sc_o[k][c] - mo[k]);
-    }
-    is[k] = 1.0f / ss;
-    io[k] = 1.0f / so;
+    ms[k] = sm_stat[k][0];
+    mo[k] = sm_stat[k][1];
+    is[k] = sm_stat[k][2];
+    io[k] = sm_stat[k][3];
   }
 
   // phase 2: pool [V | W_A V | W_B V] and combine
@@ -455,6 +463,7 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
     const int32_t* __restrict__ partner, const float* __restrict__ bias, float scale, int PS, uint16_t* __restrict__ sp) {
   // with `partner`: the lower index of a swapped pair reads the shared pooled row ONCE and writes both rows of sp
   __shared__ float sc_s[2][PA_MAX_CELLS], sc_o[2][PA_MAX_CELLS];
+  __shared__ float sm_stat[2][4];
   const int p = blockIdx.x;
   const int cells = PS * PS;
   const bool share = partner != nullptr && cells <= 64;
@@ -493,23 +502,30 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
     }
   }
   __syncthreads();
+  // softmax statistics over the cells: ONE lane per (pair, map) walks the cells in order and leaves max and 1 / sum in
+  // LDS.  (Every lane used to run all four walks for itself: 2 x 2 x cells expf per lane was a third of the kernel's
+  // vector work.)  Same order of operations, so the results are unchanged bit for bit.
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x >> 1, so = threadIdx.x & 1;
+    float mx = -__builtin_inff(), inv = 0.f;
+    if (k < npair) {
+      const float* sc = so ? sc_o[k] : sc_s[k];
+      for (int c = 0; c < cells; ++c) mx = fmaxf(mx, sc[c]);
+      float ss = 0.f;
+      for (int c = 0; c < cells; ++c) ss += expf(sc[c] - mx);
+      inv = 1.0f / ss;
+    }
+    sm_stat[k][so] = mx;
+    sm_stat[k][2 + so] = inv;
+  }
+  __syncthreads();
   float ms[2], mo[2], is[2], io[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    ms[k] = mo[k] = -__builtin_inff();
-    is[k] = io[k] = 0.f;
-    if (k >= npair) continue;
-    for (int c = 0; c < cells; ++c) {
-      ms[k] = fmaxf(ms[k], sc_s[k][c]);
-      mo[k] = fmaxf(mo[k], sc_o[k][c]);
-    }
-    float ss = 0.f, so = 0.f;
-    for (int c = 0; c < cells; ++c) {
-      ss += expf(sc_s[k][c] - ms[k]);
-      so += expf(sc_o[k][c] - mo[k]);
-    }
-    is[k] = 1.0f / ss;
-    io[k] = 1.0f / so;
+    ms[k] = sm_stat[k][0];
+    mo[k] = sm_stat[k][1];
+    is[k] = sm_stat[k][2];
+    io[k] = sm_stat[k][3];
   }
   float bv[8];
 #pragma unroll
