@@ -10,9 +10,11 @@ BASELINE.json's metric is quoted on (configs[1]: VidVRD res101xi3d50 setting, 32
 batch 8 per GPU, 20 objects / 380 pairs per clip, bf16).  Clips shard across ranks with no data-path
 collective (weak scaling); the per-video top-100 triplet records are all-gathered (RCCL) once after
 the timed region, as the sweep does.  Inputs are resident in HBM before timing.
-The steps run software-pipelined (model.overlap_steps, --overlap 0 turns it off): call n launches the backbone
-of step n beside the post-backbone chain of step n-1; the pipeline is empty when the timed region starts and
-is flushed inside it, so the K timed calls are K complete steps (first backbone and last tail un-overlapped).
+Every step replays one captured HIP graph on one stream.  --overlap 1 runs the steps software-pipelined
+(model.overlap_steps: call n launches the backbone of step n beside the post-backbone chain of step n-1; the pipeline
+is empty when the timed region starts and is flushed inside it) and --side-stream 1 puts the head's part A on a second
+stream beside the backbone: both are faster and both were found NOT bit-stable at this size, so
+the default - the number the driver records - is the serial step.
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     - dominant kernel (bf16 MFMA implicit-GEMM family): algorithmic FLOPs / launch time,
@@ -48,8 +50,11 @@ def parse():
     ap.add_argument("--objects", type=int, default=20)
     ap.add_argument("--pipeline", type=int, default=1,
                     help="captured step graphs in flight per GPU (2 measured no faster than 1: 2634 vs 2653 clips/s)")
-    ap.add_argument("--overlap", type=int, default=1,
-                    help="1: a step's post-backbone chain runs beside the next step's backbone (model.overlap_steps)")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="1: a step's post-backbone chain runs beside the next step's backbone (model.overlap_steps); "
+                         "faster, not bit-stable (see DESIGN.md)")
+    ap.add_argument("--side-stream", type=int, default=0,
+                    help="1: the head's part A runs on a second stream beside the backbone; faster, not bit-stable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch events (roofline leg)")
     return ap.parse_args()
@@ -126,7 +131,11 @@ def main():
     sd_cpu = None
     model.to(dev)
     model.graph_step = True     # serving mode: the whole step replays from one HIP graph per step signature
-    model.side_stream = True    # the HBM-bound weight-streaming FCs run on a second stream beside the backbone (-2 %)
+    # One stream, one step at a time by default.  Both concurrency modes of the model (part A on a second stream beside
+    # the backbone: --side-stream 1; the previous step's tail beside the next backbone: --overlap 1) are faster
+    # (3200 vs 2900 clips/s) and NOT bit-stable at this size: with either of them roughly one step in eight has a clip
+    # whose features differ from the serial result ("concurrent kernels"), so they are opt-in.
+    model.side_stream = bool(args.side_stream)
     model.pipeline = args.pipeline   # step graphs in flight (2: the head of step i overlaps the backbone of step i+1)
     # software-pipelined step graphs: call n runs the backbone of step n beside the rest of step n-1 and returns the
     # results of step n-1; every timed region below ends with flush_steps(), so K calls = K complete steps

@@ -189,7 +189,10 @@ class Generalized_RCNN(PackedLinears):
         self._last_step_entry = None
         # graph_step only: a call captures / replays [backbone + part A of THIS step] beside [the rest of the PREVIOUS
         # step] - the post-backbone chain is ~45 small dependent launches that leave the chip idle - and returns the
-        # previous step's results (None on the first call); `flush_steps()` finishes the pending step
+        # previous step's results (None on the first call); `flush_steps()` finishes the pending step.
+        # NOT bit-stable at bench size (8 clips x 32 frames): about one step in eight differs from the serial result
+        # in one clip (captured graphs with forked branches; the same holds for `side_stream` inside a captured step,
+        # while `side_stream` in eager mode gave 0 of 30) - DESIGN.md section 8.  Off by default, as is `side_stream`.
         self.overlap_steps = False
         self._ov_graphs = {}
         self._ov_pending = None
