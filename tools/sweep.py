@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sharded inference sweep (configs[3]): clip list -> shard_range -> overlapped steps -> one all-gather of the
+"""Sharded inference sweep (configs[3]): clip list -> shard_range -> steps (optionally overlapped) -> one all-gather of the
 top-k triplet records -> rank-0 per-video ranking.  Synthetic clips of the bench workload's shape (no dataset offline).
 
     python tools/sweep.py --clips 64 --batch 8                                   one GPU
@@ -27,7 +27,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--objects", type=int, default=20)
     ap.add_argument("--clips-per-video", type=int, default=4)
-    ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--overlap", type=int, default=0, help="1: software-pipelined steps (faster; not bit-stable at bench size, DESIGN.md section 8)")
     args = ap.parse_args()
     import torch.distributed as dist
     from trace_amd.model_builder_rel import Generalized_RCNN
