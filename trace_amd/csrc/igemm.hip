@@ -102,6 +102,24 @@ __device__ __forceinline__ int perm_row(int odd, int rho) { return ((rho >> 2) <
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// The barrier of the LDS rings.  A wave must not ARRIVE with LDS reads still in flight: behind the barrier the other
+// waves refill - by LDS-DMA - the very stage those reads came from (write-after-read).  `__builtin_amdgcn_s_barrier()`
+// alone does not order them: hipcc keeps a stage's last fragment reads in flight across it and waits for them
+// (`s_waitcnt lgkmcnt`) only in front of the MFMAs that it sank below the barrier.  Alone on a CU the reads always win the
+// race against a refill that still has an L2 round trip ahead of it; beside another kernel's workgroups that keep the CU's
+// LDS pipeline busy (a second stream or a forked graph branch) the refill can land first and the MFMA consumes bytes of
+// the NEXT K-step: one wrong 32-position wave column per ~10^5 workgroups, found in round 3 (tools/race_probe.py named the
+// launch, tools/scan_barrier_hazard.py lists every kernel whose assembly had the pattern).
+__device__ __forceinline__ void ring_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Diagnostic build switch (tools/build_variant.py): idle for TRACE_SETTLE_SLEEP x 64 cycles between the barrier that follows
+// a counted wait and the first fragment read of the stage that wait retired.
+#ifdef TRACE_SETTLE_SLEEP
+#define TRACE_SETTLE() asm volatile("s_sleep %0" ::"n"(TRACE_SETTLE_SLEEP) : "memory")
+#else
+#define TRACE_SETTLE() do {} while (0)
+#endif
+
 // Epilogue shared by the main-loop variants: bias / residual / activation / (second output) / split-K slab.
 template <int WM, int WN>
 __device__ __forceinline__ void igemm_epilogue_rows(const IgemmParams& p, f32x4 (&acc)[WM][WN], int cout0,
@@ -482,11 +500,12 @@ __global__ __launch_bounds__(256) void igemm2_bf16_kernel(const IgemmParams p) {
     if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NST >= 3 && ahead == 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();  // step ks landed for every wave; every wave is done reading step ks-1's stage
+    ring_barrier();  // step ks landed for every wave; every wave is done reading step ks-1's stage
     if (ks + NST - 1 < ksteps) {
       advance();
       issue(nxt);
     }
+    TRACE_SETTLE();
     const char* a = smem + cur * STAGE;
     const char* b = a + A_BYTES;
 #pragma unroll
@@ -749,12 +768,13 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     if (NST >= 4 && ahead >= 2) wait_vmcnt<2 * L>();
     else if (NST >= 3 && ahead >= 1) wait_vmcnt<L>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    ring_barrier();
     if (issued < ksteps) {
       const int nst_stage = st + NST - 1;
       issue(nst_stage >= NST ? nst_stage - NST : nst_stage, has_tail && issued == ksteps - 1);
       ++issued;
     }
+    TRACE_SETTLE();
     const char* sb = smem + st * STAGE;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -1009,9 +1029,14 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
     // 3136 workgroups, only at B = 8 / 32 frames, run-dependent (race screen: tests/test_i3d_gpu.py::
     // test_backbone_is_deterministic_at_bench_size).  The generic loops put six DMA issues between barrier and first
     // fragment read; this kernel only two.
+#ifdef TRACE_STEM_COUNTED
+    if (ks + 1 < ST_KSTEPS) wait_vmcnt<2>(); else wait_vmcnt<0>();
+#else
     wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+#endif
+    ring_barrier();
     if (ks + 2 < ST_KSTEPS) issue_a((ks + 2) % 3, ks + 2 == ST_KSTEPS - 1);
+    TRACE_SETTLE();
     const int abase = (ks % 3) * ST_ASTAGE;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -1224,11 +1249,12 @@ __global__ __launch_bounds__(256) void wsgemm_bf16_kernel(const IgemmParams p) {
   auto step = [&](int st) {   // st = ks % 3: register set and LDS stage of this K-step (compile-time in the callers)
     if (issued - ks - 1 >= 1) wait_vmcnt<GROUP>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    ring_barrier();
     if (issued < ksteps) {
       issue((st + 2) % 3, (st + 2) % 3);
       ++issued;
     }
+    TRACE_SETTLE();
     const char* sb = smem + st * STAGE;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
@@ -1395,9 +1421,10 @@ __global__ __launch_bounds__(256) void tconv3_bf16_kernel(const IgemmParams p) {
   auto step = [&](int k6) {
     const int dt = k6 % 3;
     wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
+    ring_barrier();
     if (s + 1 < steps) issue_a((k6 + 1) & 1, (k6 + 1) % 3);
     if (dt == 0 && s + 3 < steps) issue_b(((k6 / 3) + 1) & 1);
+    TRACE_SETTLE();
     const char* a = asm_ + (k6 & 1) * A_BYTES;
     const char* b = bsm + ((k6 / 3) & 1) * B_BYTES + dt * (Q * 128);
 #pragma unroll
@@ -1608,12 +1635,13 @@ __global__ __launch_bounds__(256 * KG) void sconv9_bf16_kernel(const IgemmParams
         case 13: wait_vmcnt<13>(); break;
         default: wait_vmcnt<0>(); break;
       }
-      __builtin_amdgcn_s_barrier();
+      ring_barrier();
       if (tap + SC_NA - 1 <= 8 || steady) issue_a((astage + SC_NA - 1) & (SC_NA - 1));
       if (steady) {
 #pragma unroll
         for (int i = tap * SL; i < (tap + 1) * SL && i < NI && tap <= 5; ++i) issue_patch(pst ^ 1, i);
       }
+      TRACE_SETTLE();
       const char* a = asm_ + astage * A_BYTES;
       if (dy == 0) {
 #pragma unroll

@@ -23,6 +23,8 @@ EPI_OUT_F32 = 4
 # When set to a list, every igemm launch (conv3d / conv3d_stem / gemm_nt) is bracketed by a pair of
 # events on the launch stream and (start, end, algorithmic_flops) is appended: bench.py's roofline leg.
 IGEMM_TRACE = None
+# diagnostics (tools/race_probe.py): a list collects (name, tensor) of the stem and every backbone block as they are launched
+PROBE = None
 
 _WS = {}
 WORKSPACE_BYTES = 64 << 20

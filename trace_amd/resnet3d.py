@@ -406,6 +406,8 @@ class ResNet3d(nn.Module):
             raise NotImplementedError("trace_amd.ResNet3d implements the inference path; call .eval()")
         with torch.no_grad():
             x = self._run_stem(x, in_ntchw)
+            if ops.PROBE is not None:
+                ops.PROBE.append(("stem", x))
             if stage_hook is not None and stage_hook[0] == -1:
                 stage_hook[1]()
             for i, name in enumerate(self.res_layers[:self.num_stages]):
@@ -413,6 +415,8 @@ class ResNet3d(nn.Module):
                 for bi, blk in enumerate(blocks):
                     # pool2 (resnet3d.py:798-799) rides in the epilogue of layer1's last conv3
                     x = blk.run(x, pool_t2=(i == 0 and self.with_pool2 and bi == len(blocks) - 1))
+                    if ops.PROBE is not None:
+                        ops.PROBE.append(("%s.%d" % (name, bi), x))
                 if stage_hook is not None and stage_hook[0] == i:
                     stage_hook[1]()
         return x
