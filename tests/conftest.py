@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    bt = os.path.join(ROOT, "tools", "native", "libsegv_bt.so")
+    if os.environ.get("TRACE_SEGV_BT") and os.path.exists(bt):      # diagnostic: native frames of a host crash
+        import ctypes
+        ctypes.CDLL(bt).segv_bt_install()
 
 
 @pytest.fixture(scope="session")

@@ -39,7 +39,7 @@ def main():
         ops.IGEMM_TRACE = None
         flops = sum(t[2] for t in tr)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.capture(g):
             out = net.forward_nhwc(x)
         g.replay()
         torch.cuda.synchronize()

@@ -23,8 +23,9 @@ def timed(fn, reps=20):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    from trace_amd import ops
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.capture(g):
         for _ in range(reps):
             fn()
     g.replay()

@@ -30,7 +30,7 @@ def bench(fn, n=20, reps=3):
         fn()
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with ops.capture(g):
         for _ in range(n):
             fn()
     g.replay()

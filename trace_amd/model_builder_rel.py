@@ -21,6 +21,8 @@ MI355X-first differences from the reference's control flow (results are the same
 Small elementwise glue (softmax over 36 classes, LayerNorm(256), gathers, sigmoid) is torch on
 the GPU; it is listed in DESIGN.md.
 """
+import collections
+import gc
 import math
 import os
 
@@ -185,16 +187,18 @@ class Generalized_RCNN(PackedLinears):
         self.graph_backbone = False
         # replay the WHOLE step (backbone + head) from one HIP graph per step signature
         self.graph_step = False
-        self._step_graphs = {}
+        # captured graphs, least recently used first; at most `max_step_graphs` step signatures stay captured per mode
+        # (a graph holds its own memory pool: a shape-varying caller would otherwise grow without bound) - `_evict`
+        self._step_graphs = collections.OrderedDict()
+        self.max_step_graphs = 8
         self._last_step_entry = None
         # graph_step only: a call captures / replays [backbone + part A of THIS step] beside [the rest of the PREVIOUS
         # step] - the post-backbone chain is ~45 small dependent launches that leave the chip idle - and returns the
-        # previous step's results (None on the first call); `flush_steps()` finishes the pending step.
-        # NOT bit-stable at bench size (8 clips x 32 frames): about one step in eight differs from the serial result
-        # in one clip (captured graphs with forked branches; the same holds for `side_stream` inside a captured step,
-        # while `side_stream` in eager mode gave 0 of 30) - DESIGN.md section 8.  Off by default, as is `side_stream`.
+        # previous step's results (None on the first call); `flush_steps()` finishes the pending step.  Off by default
+        # because it changes what a call returns; bit-identical to the serial step (tests/test_head_gpu.py, also at the
+        # bench size) since the ring barriers of the LDS-DMA kernels wait for the wave's own LDS reads
         self.overlap_steps = False
-        self._ov_graphs = {}
+        self._ov_graphs = collections.OrderedDict()
         self._ov_pending = None
         self._ov_last = None
         self._pk_epoch = 0
@@ -519,7 +523,10 @@ class Generalized_RCNN(PackedLinears):
         depth = max(1, int(self.pipeline))
         ents = self._step_graphs.get(key)
         if ents is None:
+            self._evict(self._step_graphs, dev)
             ents = self._step_graphs[key] = dict(inst=[None] * depth, calls=0)
+        else:
+            self._step_graphs.move_to_end(key)
         if len(ents["inst"]) != depth:
             raise RuntimeError("pipeline depth changed under captured step graphs: clear model._step_graphs first")
         k = ents["calls"] % depth
@@ -545,13 +552,13 @@ class Generalized_RCNN(PackedLinears):
                 cur.wait_stream(side)
                 dv = prep["upl"].views(dv_buf)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     ops.upload_slots(pinned, nb, counter, dv_buf, nb)
                     res = self._device_forward(frames_s, blob_s, fmap_s, prep, dv, topk, prd_k, False)
             ent = dict(graph=g, frames=frames_s, blob=blob_s, fmap=fmap_s, dv=dv_buf, res=res, pinned=pinned,
                        pinned_np=pinned.numpy(), counter=counter, slot_bytes=nb, seq=0, events=[None, None],
                        nbytes=prep["upl"].nbytes, stream=torch.cuda.Stream(device=dev) if depth > 1 else None,
-                       done=None, owner=ents)
+                       done=None, owner_key=key)
             ents["inst"][k] = ent
         if prep["upl"].nbytes != ent["nbytes"]:
             raise RuntimeError("upload layout changed under a captured step")
@@ -608,7 +615,10 @@ class Generalized_RCNN(PackedLinears):
             flushed = self.flush_steps()          # another step signature: no graph holds that pair of steps
         ent = self._ov_graphs.get(key)
         cur = torch.cuda.current_stream(dev)
+        if ent is not None:
+            self._ov_graphs.move_to_end(key)
         if ent is None:
+            self._evict(self._ov_graphs, dev)
             frames_s = all_frames.detach().clone(memory_format=torch.contiguous_format)
             blob_s, fmap_s = self._nhwc(blob_conv).clone(), self._nhwc(feat_map).clone()
             nb = (max(prep["upl"].nbytes, 256) + 255) // 256 * 256
@@ -635,7 +645,7 @@ class Generalized_RCNN(PackedLinears):
             graphs, hands, results = [], [None, static], []
             for w in range(2):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     main = torch.cuda.current_stream(dev)
                     # the upload is the graph's one root node: the tail (which needs nothing of this step) forks behind
                     # it - forking from the still empty capture stream and forking again before any launch on the
@@ -659,7 +669,7 @@ class Generalized_RCNN(PackedLinears):
             fgraphs, fres = [], []
             for w in range(2):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with ops.capture(g):
                     fres.append(self._device_forward(None, blob_s, fmap_s, prep, dvv[w], topk, prd_k, False, phase="b",
                                                      hand=hands[w]))
                 fgraphs.append(g)
@@ -696,6 +706,43 @@ class Generalized_RCNN(PackedLinears):
         self._ov_pending = dict(key=key, ent=ent, w=w, prep=prep, topk=topk, prd_k=prd_k)
         return outs
 
+    def _evict(self, cache, dev):
+        """Make room for one more captured step signature: drop the least recently used entries beyond
+        `max_step_graphs` - 1.  A graph is only destroyed on an idle device: nothing of it may still be in flight when
+        hipGraphExecDestroy runs, and the memory of its private pool (which tensors handed to the caller may still view)
+        goes back to the allocator only when the last such tensor dies."""
+        limit = max(1, int(self.max_step_graphs))
+        if len(cache) < limit:
+            return
+        if cache is self._ov_graphs and self._ov_pending is not None:
+            raise RuntimeError("a step is pending in the overlapped pipeline: call flush_steps() first")   # callers flush on a signature change
+        torch.cuda.synchronize(dev)
+        while len(cache) >= limit:
+            _, ent = cache.popitem(last=False)
+            if cache is self._step_graphs:
+                if any(self._last_step_entry is e for e in ent["inst"]):
+                    self._last_step_entry = None
+            elif self._ov_last is ent:
+                self._ov_last = None
+            del ent
+        gc.collect()               # graph objects die here, on the idle device - never later inside a capture (ops.capture)
+        torch.cuda.synchronize(dev)
+
+    def drop_graphs(self):
+        """Destroy every captured step graph (finishing a pending overlapped step first, whose results are returned).
+        Tensors of earlier results stay valid; their memory is released when they die."""
+        outs = self.flush_steps()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self._step_graphs.clear()
+        self._ov_graphs.clear()
+        self._last_step_entry = None
+        self._ov_last = None
+        gc.collect()               # as in _evict
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return outs
+
     def flush_steps(self):
         """Finish the step still pending in the overlapped pipeline (a captured graph of the tail alone, on the current
         stream) and return its per-clip dicts; None when nothing is pending."""
@@ -722,7 +769,7 @@ class Generalized_RCNN(PackedLinears):
             e = self._ov_last
             return e["frames"], e["blob"], e["fmap"]
         e = self._last_step_entry
-        ents = e["owner"]
+        ents = self._step_graphs[e["owner_key"]]
         nxt = ents["inst"][ents["calls"] % len(ents["inst"])]
         if nxt is None:
             nxt = e

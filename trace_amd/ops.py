@@ -26,6 +26,42 @@ IGEMM_TRACE = None
 # diagnostics (tools/race_probe.py): a list collects (name, tensor) of the stem and every backbone block as they are launched
 PROBE = None
 
+
+
+class capture:
+    """`with ops.capture(g):` = `with torch.cuda.graph(g):` with Python's cyclic garbage collector out of the way.
+    A torch.cuda.CUDAGraph that dies INSIDE another graph's stream capture runs hipGraphExecDestroy + hipDeviceSynchronize
+    there (its destructor, ROCm build), which the capture does not survive: an abort in the destructor, or a captured graph
+    that later segfaults in hipGraphLaunch.  Graph objects in dead reference cycles die whenever the collector happens to
+    run (torch 2.10 no longer collects at capture entry), so: collect now, on the idle device, and keep the collector off
+    until the capture has ended."""
+
+    def __init__(self, graph, **kw):
+        self.graph, self.kw = graph, kw
+
+    def __enter__(self):
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+        self.ctx = torch.cuda.graph(self.graph, **self.kw)
+        try:
+            return self.ctx.__enter__()
+        except BaseException:
+            if self.was:
+                gc.enable()
+            raise
+
+    def __exit__(self, *a):
+        import gc
+        try:
+            return self.ctx.__exit__(*a)
+        finally:
+            if self.was:
+                gc.enable()
+
+
 _WS = {}
 WORKSPACE_BYTES = 64 << 20
 _RECORDING = None

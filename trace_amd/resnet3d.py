@@ -468,7 +468,7 @@ class ResNet3d(nn.Module):
                 self.forward_ndhwc(xin, in_ntchw)        # packs weights, sizes the split-K workspace
             torch.cuda.current_stream(x.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.capture(g):
                 out = self.forward_ndhwc(xin, in_ntchw)
             ent = (g, xin, out, _PACK_EPOCH[0])
             self._graphs[key] = ent
