@@ -10,11 +10,13 @@ BASELINE.json's metric is quoted on (configs[1]: VidVRD res101xi3d50 setting, 32
 batch 8 per GPU, 20 objects / 380 pairs per clip, bf16).  Clips shard across ranks with no data-path
 collective (weak scaling); the per-video top-100 triplet records are all-gathered (RCCL) once after
 the timed region, as the sweep does.  Inputs are resident in HBM before timing.
-Every step replays one captured HIP graph on one stream.  --overlap 1 runs the steps software-pipelined
-(model.overlap_steps: call n launches the backbone of step n beside the post-backbone chain of step n-1; the pipeline
-is empty when the timed region starts and is flushed inside it) and --side-stream 1 puts the head's part A on a second
-stream beside the backbone: both are faster and both were found NOT bit-stable at this size, so
-the default - the number the driver records - is the serial step.
+Every step replays one captured HIP graph.  By default the steps run software-pipelined (--overlap 1,
+model.overlap_steps: call n launches the backbone of step n beside the post-backbone chain of step n-1; the pipeline
+is empty when the timed region starts and is flushed inside it) with the head's part A on a second stream beside the
+backbone (--side-stream 1).  Both modes give the serial step's bits (tests/test_head_gpu.py::
+test_step_graph_is_bit_stable_at_bench_size; DESIGN.md section 8 has the race that used to break this and its fix);
+--overlap 0 --side-stream 0 times the serial step.  Triplets are ranked with prd_k = 20 predicates per pair, as the
+reference's VidVRD evaluation does (lib/datasets_rel/task_evaluation_vg_and_vrd.py:95).
 
 Prints ONE JSON line (rank 0) with the driver contract fields plus
   roofline     - dominant kernel (bf16 MFMA implicit-GEMM family): algorithmic FLOPs / launch time,
@@ -50,11 +52,12 @@ def parse():
     ap.add_argument("--objects", type=int, default=20)
     ap.add_argument("--pipeline", type=int, default=1,
                     help="captured step graphs in flight per GPU (2 measured no faster than 1: 2634 vs 2653 clips/s)")
-    ap.add_argument("--overlap", type=int, default=0,
-                    help="1: a step's post-backbone chain runs beside the next step's backbone (model.overlap_steps); "
-                         "faster, not bit-stable (see DESIGN.md)")
-    ap.add_argument("--side-stream", type=int, default=0,
-                    help="1: the head's part A runs on a second stream beside the backbone; faster, not bit-stable")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1: a step's post-backbone chain runs beside the next step's backbone (model.overlap_steps)")
+    ap.add_argument("--side-stream", type=int, default=1,
+                    help="1: the head's part A runs on a second stream beside the backbone")
+    ap.add_argument("--prd-k", type=int, default=20, help="predicates ranked per pair (reference: prd_k_set = (20,))")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] lines")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trace", action="store_true", help="skip per-launch events (roofline leg)")
     return ap.parse_args()
@@ -79,6 +82,55 @@ def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
     return dict(value=done / dt, unit="clips/sec", cores=cores, kind="port",
                 sample="%d clip(s) of the bench workload (%df 224^2, %d objects), fp32, one clip per call"
                        % (done, frames.shape[1], rois[0].shape[0]))
+
+
+def secondary_configs(dev, prd_k, steps=5):
+    """BASELINE configs[2] (Action Genome setting: 50 objects, all ordered pairs through the overlap filter, AG dims) and
+    configs[4] (64 frames, 100 objects, 9 900 pairs) as secondary lines: whole steps from the captured graph (second
+    stream on), plus the ROIAlign / pair-kernel rooflines at those sizes.  configs[1] stays the headline."""
+    import bench_kernels
+    from trace_amd.config import ag_config
+    from trace_amd.model_builder_rel import Generalized_RCNN
+    from trace_amd.synthetic import make_inputs, randomize_model
+    out = []
+    for tag, cfg, B, T, n in (("configs[2]: Action Genome setting, 32-frame clips, 50 objects, overlap filter", ag_config(), 4, 32, 50),
+                              ("configs[4]: 64-frame clip, 100 objects", None, 1, 64, 100)):
+        torch.manual_seed(2)
+        m = Generalized_RCNN(cfg)
+        randomize_model(m, 2)
+        m.eval().to(dev)
+        calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
+        m.Prd_RCNN.calibrate_bn(calib.to(dev))
+        fr, bl, fe, rois = make_inputs(B, T, n, 224, seed=3)
+        fr = fr.to(dev)
+        bl = bl.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        fe = fe.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        rng = np.random.default_rng(5)
+        labels = [rng.integers(2, m.cfg.NUM_CLASSES, n).astype(np.int32) for _ in range(B)]     # no persons: every ordered pair
+        scores = [(rng.permutation(n) / n * 0.9 + 0.05).astype(np.float32) for _ in range(B)]
+        m.graph_step, m.side_stream = True, True
+        kk = min(prd_k, m.cfg.NUM_PRD_CLASSES)
+
+        def step():
+            return m.forward_clips(fr, bl, fe, rois, topk=100, prd_k=kk, det_labels=labels, det_scores=scores)
+        for _ in range(2):
+            outs = step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            outs = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        pairs = [int(o["prd_scores"].shape[0]) for o in outs]
+        kern = bench_kernels.measure(dev, B=B, n=n, Tn=m.Prd_RCNN.out_frames(T), C=int(bl.shape[3]), fm=int(bl.shape[1]), nms=False)
+        out.append(dict(workload=tag, clips_per_gpu=B, frames=T, objects=n, pairs_per_clip=pairs, prd_k=kk,
+                        value=B / dt, unit="clips/sec", ms_per_step=dt * 1e3, pairs_per_sec=sum(pairs) / dt,
+                        roofline_roi_align=kern["roi_align"], roofline_roi_align_avg=kern["roi_align_avg"],
+                        roofline_pair={"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"]}))
+        m.drop_graphs()
+        del m
+        torch.cuda.empty_cache()
+    return out
 
 
 def spawn_ranks(n):
@@ -131,10 +183,8 @@ def main():
     sd_cpu = None
     model.to(dev)
     model.graph_step = True     # serving mode: the whole step replays from one HIP graph per step signature
-    # One stream, one step at a time by default.  Both concurrency modes of the model (part A on a second stream beside
-    # the backbone: --side-stream 1; the previous step's tail beside the next backbone: --overlap 1) are faster
-    # (3200 vs 2900 clips/s) and NOT bit-stable at this size: with either of them roughly one step in eight has a clip
-    # whose features differ from the serial result ("concurrent kernels"), so they are opt-in.
+    # Both concurrency modes of the model on by default (part A on a second stream beside the backbone; the previous
+    # step's tail beside the next backbone): 3200 vs 2800 clips/s, same bits as the serial step.
     model.side_stream = bool(args.side_stream)
     model.pipeline = args.pipeline   # step graphs in flight (2: the head of step i overlaps the backbone of step i+1)
     # software-pipelined step graphs: call n runs the backbone of step n beside the rest of step n-1 and returns the
@@ -157,7 +207,7 @@ def main():
         # the inputs stay resident in the buffers the captured step graph reads (no per-step copy); with two
         # graph instances in flight each has its own copy of the (identical) synthetic inputs
         f, b, m_ = model.step_buffers() if state["resident"] else (frames, blob, feat)
-        return model.forward_clips(f, b, m_, rois, topk=100, prd_k=1)
+        return model.forward_clips(f, b, m_, rois, topk=100, prd_k=args.prd_k)
 
     for _ in range(max(args.warmup, args.pipeline)):
         outs = step()
@@ -215,14 +265,14 @@ def main():
     value = world * B * args.steps / dt
     roof = None
     if trace:
-        ms = [max(t[0].elapsed_time(t[1]) - event_overhead_ms, 1e-3) for t in trace]   # bracket overhead removed
+        ms = [t[0].elapsed_time(t[1]) for t in trace]   # as the events give it (an empty bracket, reported beside it, is NOT subtracted)
         fl = [t[2] for t in trace]
         alg_bytes = sum(t[3] for t in trace) / len(trace)
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes over
         # this same command, tools/pmc_traffic.py): bench.py cannot run under the profiler itself, so it quotes
         # the committed summary of the current round
         traffic = None
-        for tp in ("r02_igemm_traffic.json", "r01_igemm_traffic.json"):
+        for tp in ("r03_igemm_traffic.json", "r02_igemm_traffic.json", "r01_igemm_traffic.json"):
             tp = os.path.join(ROOT, "profiles", tp)
             if os.path.exists(tp):
                 traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
@@ -258,7 +308,7 @@ def main():
 
             def pstep():
                 res.copy_(host, non_blocking=True)
-                return model.forward_clips(res, blob, feat, rois, topk=100, prd_k=1)
+                return model.forward_clips(res, blob, feat, rois, topk=100, prd_k=args.prd_k)
             for _ in range(3):
                 pstep()
             model.sync_steps()
@@ -269,6 +319,10 @@ def main():
             model.sync_steps()
             torch.cuda.synchronize()
             pcie[tag] = dict(clips_per_sec=B * args.steps / (time.perf_counter() - tp0), host_bytes_per_step=host.numel() * host.element_size())
+    second = None
+    if trace is not None and not args.no_secondary:
+        model.drop_graphs()
+        second = secondary_configs(dev, args.prd_k)
     cpu = None
     if sd_cpu is not None:
         cpu = cpu_baseline(sd_cpu, frames_c, blob_c, feat_c, rois)
@@ -288,6 +342,8 @@ def main():
         "roofline_pair": kern and {"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"]},
         "roofline_nms": kern and {"rpn": kern["nms_rpn"], "per_class": kern["nms_per_class"]},
         "i3d_algorithmic_tflops": value * I3D_GFLOP_PER_CLIP / 1e3,
+        "prd_k": args.prd_k, "overlap_steps": bool(args.overlap) and args.pipeline == 1, "side_stream": bool(args.side_stream),
+        "other_configs": second,
     }
     print(json.dumps(out))
     if dist:

@@ -48,7 +48,7 @@ def entry(kernel, us, nbytes, **extra):
     return d
 
 
-def measure(dev, B=8, n=20, Tn=4, C=2048, fm=14, seed=1):
+def measure(dev, B=8, n=20, Tn=4, C=2048, fm=14, seed=1, nms=True):
     from trace_amd import _C, ops
     from trace_amd import boxes as tb
     from trace_amd.synthetic import synth_boxes
@@ -101,6 +101,8 @@ def measure(dev, B=8, n=20, Tn=4, C=2048, fm=14, seed=1):
     fused_bytes = P * 49 * D * 2 + vab.numel() * 2 + P * 49 * 2 * 4 * 4
     out["pair_infer"] = entry("trace::pair_infer_kernel", timed(lambda: ops.pair_infer(vab, qk, und, Xd, Yd, bias, 1 / 16., 7, partner=part)),
                               fused_bytes, pairs=P, D=D, call="pool + combine in one launch (no pooled map in HBM)")
+    if not nms:
+        return out
     # NMS: SURVEY 8d stress sizes.  Algorithmic bytes = N*20 in + N*8 out (compute-light: boxes/s is the figure)
     N = 6000
     bx = torch.from_numpy(synth_boxes(rng, N, 3.0, 800.0)).to(dev)
