@@ -84,7 +84,7 @@ def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
                        % (done, frames.shape[1], rois[0].shape[0]))
 
 
-def secondary_configs(dev, prd_k, steps=5):
+def secondary_configs(dev, prd_k, steps=5, only=None, kernels=True):
     """BASELINE configs[2] (Action Genome setting: 50 objects, all ordered pairs through the overlap filter, AG dims) and
     configs[4] (64 frames, 100 objects, 9 900 pairs) as secondary lines: whole steps from the captured graph (second
     stream on), plus the ROIAlign / pair-kernel rooflines at those sizes.  configs[1] stays the headline."""
@@ -95,6 +95,8 @@ def secondary_configs(dev, prd_k, steps=5):
     out = []
     for tag, cfg, B, T, n in (("configs[2]: Action Genome setting, 32-frame clips, 50 objects, overlap filter", ag_config(), 4, 32, 50),
                               ("configs[4]: 64-frame clip, 100 objects", None, 1, 64, 100)):
+        if only is not None and only not in tag:
+            continue
         torch.manual_seed(2)
         m = Generalized_RCNN(cfg)
         randomize_model(m, 2)
@@ -122,6 +124,9 @@ def secondary_configs(dev, prd_k, steps=5):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         pairs = [int(o["prd_scores"].shape[0]) for o in outs]
+        if not kernels:
+            out.append(dict(workload=tag, value=B / dt, ms_per_step=dt * 1e3, pairs_per_clip=pairs))
+            continue
         kern = bench_kernels.measure(dev, B=B, n=n, Tn=m.Prd_RCNN.out_frames(T), C=int(bl.shape[3]), fm=int(bl.shape[1]), nms=False)
         out.append(dict(workload=tag, clips_per_gpu=B, frames=T, objects=n, pairs_per_clip=pairs, prd_k=kk,
                         value=B / dt, unit="clips/sec", ms_per_step=dt * 1e3, pairs_per_sec=sum(pairs) / dt,

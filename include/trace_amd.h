@@ -257,6 +257,17 @@ int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N,
                        void* workspace, size_t workspace_bytes,
                        trace_stream_t stream);
 
+/* Workspace sizing for the conv / GEMM family (SURVEY.md 8b "trace_workspace_bytes_*"; the reference's kernels allocate
+ * their own scratch through ATen, e.g. Detectron_pytorch/lib/model/csrc/cuda/ROIAlign_cuda.cu:271 - here the caller
+ * owns it).  Returns the split-K scratch the launch rules WANT for the problem: with at least that many bytes the plan
+ * (tile, number of K slices and therefore the f32 summation order of the result) does not depend on the size of the
+ * caller's buffer; with a smaller buffer fewer slices are used, with none the K loop is not split.  0 = no scratch
+ * used.  Pure host functions: no device call, no launch. */
+size_t trace_gemm_workspace_bytes(int M, int N, int K, int lda, int ldb, int ldc, int batch, int epilogue);
+size_t trace_conv3d_workspace_bytes(int N, int Ti, int Hi, int Wi, int Cin, int Cout, int kt, int kh, int kw,
+                                    int st, int sh, int sw, int pt, int ph, int pw, int dt, int dh, int dw,
+                                    int epilogue);
+
 /* trace_gemm_bf16_nt with the epilogue forms the relation head chains between its Linear layers
  * (model_builder_rel.py:938-952, 1018-1024, 1039-1069; cluster_tree3d.py:192-201, 293-330), so that a
  * sum or activation that the reference computes as a separate torch op costs no launch of its own:

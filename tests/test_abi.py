@@ -52,3 +52,18 @@ def test_empty_nms_returns_empty_cpu_tensor():
     from trace_amd import roi_layers
     out = roi_layers.nms(torch.zeros(0, 4), torch.zeros(0), 0.5)
     assert out.numel() == 0 and out.dtype == torch.int64 and out.device.type == "cpu"
+
+
+def test_gemm_workspace_bytes_is_the_split_k_plan():
+    """trace_gemm_workspace_bytes / trace_conv3d_workspace_bytes (host-only): the scratch the launch rules want - K slices
+    x M x N f32 slabs for the deep-K weight-streaming FCs of the relation head, nothing for batched or shallow problems."""
+    from trace_amd import _lib
+    l = _lib.lib()
+    EPI_WTILED = 64
+    fc1 = l.trace_gemm_workspace_bytes(160, 3072, 100352, 100352, 100352, 3072, 1, EPI_WTILED)
+    assert fc1 % (160 * 3072 * 4) == 0 and 8 <= fc1 // (160 * 3072 * 4) <= 32
+    assert l.trace_gemm_workspace_bytes(6272, 1024, 256, 256, 256, 1024, 1, 0) == 0          # one round of K: no split
+    assert l.trace_gemm_workspace_bytes(512, 512, 200, 200, 200, 512, 8, 0) == 0             # batched: never split
+    one_clip = l.trace_conv3d_workspace_bytes(1, 1, 14, 14, 2048, 512, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1)
+    assert one_clip % (196 * 512 * 4) == 0 and one_clip > 0
+    assert l.trace_conv3d_workspace_bytes(8, 4, 14, 14, 512, 512, 1, 3, 3, 1, 1, 1, 0, 2, 2, 1, 2, 2, 1) == 0   # patch-shared 3x3

@@ -134,3 +134,29 @@ def test_two_rank_gloo_sweep_with_uneven_shards():
     for p in ps:
         p.join(60)
     assert [r[1] for r in res] == [True, True]
+
+
+def test_pack_triplets_matches_the_per_clip_loop():
+    """The vectorised packer against the plain per-clip loop it replaced: ragged k, ragged pair counts, clip offset."""
+    import numpy as np
+    import torch
+    from trace_amd.dist import RECORD_WIDTH, pack_triplets
+    rng = np.random.default_rng(3)
+    outs, topk = [], 7
+    for k, P in ((7, 12), (3, 4), (0, 2), (5, 30)):
+        pair = torch.from_numpy(rng.integers(0, P, k))
+        outs.append(dict(prd_scores=torch.zeros((P, 3)), top_scores=torch.from_numpy(rng.random(k).astype(np.float32)),
+                         top_sbj=torch.from_numpy(rng.integers(1, 36, k)), top_prd=torch.from_numpy(rng.integers(0, 132, k)),
+                         top_obj=torch.from_numpy(rng.integers(1, 36, k)), top_pair=pair,
+                         sbj_rois=rng.random((P, 5)).astype(np.float32), obj_rois=rng.random((P, 5)).astype(np.float32)))
+    want = torch.zeros((len(outs), topk, RECORD_WIDTH))
+    for b, d in enumerate(outs):
+        k = int(d["top_scores"].shape[0])
+        pair = d["top_pair"].numpy()
+        want[b, :k, 0] = d["top_scores"]
+        want[b, :k, 1], want[b, :k, 2], want[b, :k, 3] = d["top_sbj"].float(), d["top_prd"].float(), d["top_obj"].float()
+        want[b, :k, 4:8] = torch.from_numpy(d["sbj_rois"][pair, 1:5])
+        want[b, :k, 8:12] = torch.from_numpy(d["obj_rois"][pair, 1:5])
+        want[b, :, 12] = 40 + b
+        want[b, :, 13] = k
+    assert torch.equal(pack_triplets(outs, topk, clip_offset=40), want)

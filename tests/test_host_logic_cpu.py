@@ -84,3 +84,27 @@ def test_swapped_pair_index():
     assert swapped_pair_index([0], [0]).tolist() == [-1]
     assert swapped_pair_index([], []).shape == (0,)
     assert swapped_pair_index([0, 0, 1, 1], [1, 1, 0, 0]).tolist() == [2, -1, 0, -1]
+
+
+def test_relpn_pairs_of_the_detected_box_branch():
+    """relpn_heads.py:71-105 through the model's host prep: one detection pairs with itself (self pairs are only removed
+    when there are two or more, :79-84 - so the score-threshold loop of model_builder_rel.py:911-935 ends as soon as
+    there is a detection); the overlap filter applies while lim_score >= 0.015 and never empties the list."""
+    import trace_amd.model_builder_rel as mb
+    from trace_amd.config import ag_config
+    cfg = ag_config()
+    cfg.MLP_HEAD_DIM = 64                 # host logic only: keep the FC layers small
+    model = mb.Generalized_RCNN(cfg, conv_bodies=False).eval()
+    z = np.zeros((3, 1), np.float32)
+    boxes = np.array([[10, 10, 60, 60], [40, 40, 100, 100], [150, 150, 200, 200]], np.float32)     # 0-1 overlap, 2 is alone
+    rois = [np.hstack((z, boxes))]
+    lab, sc = [np.array([5, 7, 9])], [np.array([.9, .8, .7], np.float32)]              # no person: every ordered pair
+    pairs = lambda p: sorted(zip(p["pairs"][0][0].tolist(), p["pairs"][0][1].tolist()))
+    assert pairs(model._host_prep(rois, 1, 1.0, 1.0, lab, sc, lim_score=0.05)) == [(0, 1), (1, 0)]
+    assert len(pairs(model._host_prep(rois, 1, 1.0, 1.0, lab, sc, lim_score=0.01))) == 6           # filter skipped (:94)
+    far = [np.hstack((z[:2], boxes[[0, 2]]))]
+    assert pairs(model._host_prep(far, 1, 1.0, 1.0, [lab[0][:2]], [sc[0][:2]], lim_score=0.05)) == [(0, 1), (1, 0)]   # :99
+    one = [np.hstack((z[:1], boxes[:1]))]
+    assert pairs(model._host_prep(one, 1, 1.0, 1.0, [np.array([1])], [sc[0][:1]], lim_score=0.05)) == [(0, 0)]
+    person = [np.array([1, 7, 9])]                                                               # persons only as subjects
+    assert pairs(model._host_prep(rois, 1, 1.0, 1.0, person, sc, lim_score=0.01)) == [(0, 1), (0, 2)]

@@ -225,3 +225,29 @@ def test_maxpool3d():
         ref = F.max_pool3d(x.float(), k, s, p)
         got = ops.maxpool3d(xl, k, s, p).float().permute(0, 4, 1, 2, 3).cpu()
         assert torch.equal(got, ref)
+
+
+def test_split_k_plan_is_fixed_by_trace_gemm_workspace_bytes():
+    """A workspace of exactly trace_gemm_workspace_bytes(...) gives the bits of an arbitrarily large one (the plan - and
+    with it the f32 summation order - only changes BELOW that size), and a smaller one still gives a valid result."""
+    from trace_amd import _lib as L
+    from trace_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 96, 256, 16384
+    A = (torch.randn((M, K), device=DEV) * 0.1).to(torch.bfloat16)
+    B = (torch.randn((N, K), device=DEV) * 0.1).to(torch.bfloat16)
+    need = int(L.lib().trace_gemm_workspace_bytes(M, N, K, K, K, N, 1, 0))
+    assert need > 0 and need % (M * N * 4) == 0
+
+    def run(nbytes):
+        ws = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=DEV)
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().trace_gemm_bf16_nt(L.ptr(A), L.ptr(B), M, N, K, K, K, N, 1, 0, 0, 0, 1.0, None, None, 0, L.ptr(out),
+                                           L.ptr(ws) if nbytes else None, nbytes, L.stream()), "gemm")
+        torch.cuda.synchronize()
+        return out
+    big, exact, small, none = run(64 << 20), run(need), run(need // 2), run(0)
+    assert torch.equal(big, exact)
+    ref = A.float() @ B.float().t()
+    for got in (exact, small, none):
+        assert float((got.float() - ref).norm() / ref.norm()) < 1e-2

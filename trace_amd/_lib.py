@@ -55,6 +55,8 @@ SIGNATURES = {
     "trace_bbox_overlaps": (c_int, [P, c_int, P, c_int, P, P]),
     "trace_bbox_pair_overlaps": (c_int, [P, P, c_int, P, P]),
     "trace_relpn_pairs": (c_int, [P, c_int, P, P, P, P]),
+    "trace_gemm_workspace_bytes": (c_size_t, [c_int] * 8),
+    "trace_conv3d_workspace_bytes": (c_size_t, [c_int] * 19),
     "trace_clip_to_ndhwc_bf16": (c_int, [P] + [c_int] * 13 + [P, P]),
     "trace_conv3d_stem_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 11 + [P, P]),
     "trace_conv3d_stem16_f32": (c_int, [P] + [c_int] * 6 + [P, P] + [c_int] * 5 + [P, P]),

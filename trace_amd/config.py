@@ -29,6 +29,10 @@ class TraceConfig:
     DETECTIONS_PER_IM: int = 100
     TEST_NMS: float = 0.5
     TEST_SCORE_THRESH: float = 0.05   # lib/core/config.py TEST.SCORE_THRESH
+    FRAMES_INTERVAL: int = 4          # configs/vidvrd/...gt_boxes...yaml:69-70 (HALF_NUMBER_OF_FRAMES 8, interval 4)
+    TEMPORAL_SCALES: int = 224        # short side of the clip frames (test_engine_rel.py:468)
+    TEST_SCALE: int = 800             # key-frame short side / cap (TEST.SCALE, TEST.MAX_SIZE)
+    TEST_MAX_SIZE: int = 1333
     dataset: str = "vidvrd"
 
 

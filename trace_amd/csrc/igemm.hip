@@ -70,6 +70,7 @@ struct IgemmParams {
   int f_C, f_T, f_H, f_W, f_ntchw;
   const uint8_t* in_u8;  // stem16 only: uint8 frames (N,T,H,W,C), channels-last as decoded; value = (float)u8 - u8_mean[c]
   float u8_mean[3];
+  int dry;           // 1: plan only (trace_*_workspace_bytes): launch nothing, leave the split-K scratch the plan wants in g_dry_bytes
   int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
 };
 
@@ -1291,6 +1292,8 @@ __global__ __launch_bounds__(256) void wsgemm_bf16_kernel(const IgemmParams p) {
   }
 }
 
+static thread_local size_t g_dry_bytes = 0;
+
 template <int WN>
 static int launch_wsgemm(IgemmParams& p, hipStream_t s, int ksplit_req) {
   const int ksteps = p.Ktot / BK;
@@ -1304,6 +1307,10 @@ static int launch_wsgemm(IgemmParams& p, hipStream_t s, int ksplit_req) {
   p.ks_per = ceil_div(ksteps, ks);
   p.ksplit = ceil_div(ksteps, p.ks_per);
   p.partial = (float*)p.ws;
+  if (p.dry) {
+    g_dry_bytes = (size_t)p.ksplit * p.M * p.Cout * sizeof(float);
+    return 0;
+  }
   constexpr int LDS = 3 * 16 * WN * 128;
   TRACE_LDS_OPT_IN((&wsgemm_bf16_kernel<WN>), LDS, "igemm");
   hipLaunchKernelGGL((wsgemm_bf16_kernel<WN>), dim3(tiles_n, p.ksplit), dim3(256), LDS, s, p);
@@ -1472,6 +1479,7 @@ static int launch_tconv3(IgemmParams& p, int N, hipStream_t s) {
     set_error("conv3d: grid too large");
     return 1;
   }
+  if (p.dry) return 0;   // no scratch
   TRACE_LDS_OPT_IN((&tconv3_bf16_kernel<WM, LOGQ>), LDS, "igemm");
   hipLaunchKernelGGL((tconv3_bf16_kernel<WM, LOGQ>), dim3((unsigned)nwg), dim3(256), LDS, s, p);
   return check_launch("conv3d_tconv3");
@@ -1708,6 +1716,7 @@ static int launch_sconv9_kg(IgemmParams& p, long long nwg, hipStream_t s) {
   p.tiles_n = ceil_div(p.Cout, 64);
   p.ksplit = 1;
   p.ks_per = 0;
+  if (p.dry) return 0;   // no scratch
   TRACE_LDS_OPT_IN((&sconv9_bf16_kernel<WN, D, KG>), LDS_MAX, "igemm");
   const int lds = (p.Crun > BK ? 2 : 1) * PATCH_BYTES + SC_NA * 64 * 128;   // one 64-channel chunk: no second patch stage
   hipLaunchKernelGGL((sconv9_bf16_kernel<WN, D, KG>), dim3((unsigned)nwg), dim3(256 * KG), lds, s, p);
@@ -1785,6 +1794,10 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
       p.ksplit = ceil_div(ksteps, p.ks_per);
       p.partial = (float*)p.ws;
     }
+  }
+  if (p.dry) {
+    g_dry_bytes = p.ksplit > 1 ? (size_t)p.ksplit * p.M * p.Cout * sizeof(float) : 0;
+    return 0;
   }
   p.xcd_slices = (p.ksplit >= 8 && p.ksplit % 8 == 0 && batch == 1) ? 1 : 0;
   const dim3 grid((unsigned)nblk, p.ksplit, batch);
@@ -1954,12 +1967,12 @@ extern "C" int trace_igemm_tune(int tile, int nst, int ksplit) {
   return 0;
 }
 
-extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi, int Wi, int Cin,
-                                       const uint16_t* w, const float* bias, int Cout, int kt,
-                                       int kh, int kw, int st, int sh, int sw, int pt, int ph,
-                                       int pw, int dt, int dh, int dw, const uint16_t* residual,
-                                       int epilogue, void* out, void* workspace,
-                                       size_t workspace_bytes, trace_stream_t stream) {
+static int conv3d_impl(const uint16_t* in, int N, int Ti, int Hi, int Wi, int Cin,
+                       const uint16_t* w, const float* bias, int Cout, int kt,
+                       int kh, int kw, int st, int sh, int sw, int pt, int ph,
+                       int pw, int dt, int dh, int dw, const uint16_t* residual,
+                       int epilogue, void* out, void* workspace,
+                       size_t workspace_bytes, trace_stream_t stream, int dry) {
   TRACE_REQUIRE(N >= 0 && Ti > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, "conv3d: bad shape");
   TRACE_REQUIRE(Cin % 8 == 0, "conv3d: Cin=%d must be a multiple of 8", Cin);
   TRACE_REQUIRE(Cout % 8 == 0, "conv3d: Cout=%d must be a multiple of 8", Cout);
@@ -2006,7 +2019,31 @@ extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi
   }
   p.ws = ((uintptr_t)workspace & 15) ? nullptr : workspace;
   p.ws_bytes = workspace_bytes;
+  p.dry = dry;
   return launch_igemm(p, 1, (hipStream_t)stream);
+}
+
+extern "C" int trace_conv3d_igemm_bf16(const uint16_t* in, int N, int Ti, int Hi, int Wi, int Cin,
+                                       const uint16_t* w, const float* bias, int Cout, int kt,
+                                       int kh, int kw, int st, int sh, int sw, int pt, int ph,
+                                       int pw, int dt, int dh, int dw, const uint16_t* residual,
+                                       int epilogue, void* out, void* workspace,
+                                       size_t workspace_bytes, trace_stream_t stream) {
+  return conv3d_impl(in, N, Ti, Hi, Wi, Cin, w, bias, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, dt, dh, dw, residual, epilogue,
+                     out, workspace, workspace_bytes, stream, 0);
+}
+
+// The split-K scratch the launch rules WANT for this problem: with at least this much workspace the plan (tile, K slices,
+// hence the f32 summation order) does not depend on the caller's buffer; with less, fewer slices are used (or none).
+extern "C" size_t trace_conv3d_workspace_bytes(int N, int Ti, int Hi, int Wi, int Cin, int Cout, int kt, int kh, int kw,
+                                               int st, int sh, int sw, int pt, int ph, int pw, int dt, int dh, int dw,
+                                               int epilogue) {
+  static const uint4 dummy = {};
+  const uint16_t* a = reinterpret_cast<const uint16_t*>(&dummy);
+  g_dry_bytes = 0;
+  const int rc = conv3d_impl(a, N, Ti, Hi, Wi, Cin, a, nullptr, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, dt, dh, dw,
+                             (epilogue & TRACE_EPI_RESIDUAL) ? a : nullptr, epilogue, (void*)a, (void*)a, (size_t)-1, nullptr, 1);
+  return rc ? 0 : g_dry_bytes;
 }
 
 extern "C" int trace_conv3d_stem_bf16(const uint16_t* in_padded, int N, int Tp, int Hp, int Wp, int Cp,
@@ -2141,7 +2178,7 @@ static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K,
                      long long strideA, long long strideB, long long strideC, float alpha, const float* bias,
                      long long strideBias, const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
                      void* workspace, size_t workspace_bytes, trace_stream_t stream, const uint16_t* A2 = nullptr,
-                     int lda2 = 0, int K1 = 0) {
+                     int lda2 = 0, int K1 = 0, int dry = 0) {
   TRACE_REQUIRE(M >= 0 && N >= 0 && K > 0 && batch >= 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
   if (M == 0 || N == 0 || batch == 0) return 0;
   TRACE_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm: K, lda, ldb must be multiples of 8");
@@ -2193,7 +2230,20 @@ static int gemm_impl(const uint16_t* A, const uint16_t* Bm, int M, int N, int K,
     p.pix2 = lda2;
     p.k_switch = K1 / BK;
   }
+  p.dry = dry;
   return launch_igemm(p, batch, (hipStream_t)stream);
+}
+
+// Split-K scratch wanted by trace_gemm_bf16_nt / _ex for this problem (see trace_conv3d_workspace_bytes); 0 when the
+// launch rules do not split K (batched problems never do).
+extern "C" size_t trace_gemm_workspace_bytes(int M, int N, int K, int lda, int ldb, int ldc, int batch, int epilogue) {
+  static const uint4 dummy = {};
+  const uint16_t* a = reinterpret_cast<const uint16_t*>(&dummy);
+  g_dry_bytes = 0;
+  const int rc = gemm_impl(a, a, M, N, K, lda, ldb, ldc, batch, 0, 0, 0, 1.0f, nullptr, 0,
+                           (epilogue & (TRACE_EPI_RESIDUAL | TRACE_EPI_RES_POST)) ? a : nullptr, epilogue, (void*)a, nullptr, 0,
+                           (void*)a, (size_t)-1, nullptr, nullptr, 0, 0, 1);
+  return rc ? 0 : g_dry_bytes;
 }
 
 extern "C" int trace_gemm_bf16_nt(const uint16_t* A, const uint16_t* Bm, int M, int N, int K, int lda,

@@ -18,20 +18,40 @@ def shard_range(n_items, rank, world):
 
 
 def pack_triplets(outs, topk, clip_offset=0):
-    """Per-clip return dicts (with top_* keys) -> (B, topk, RECORD_WIDTH) f32 tensor, zero padded."""
-    dev = outs[0]["prd_scores"].device if len(outs) else torch.device("cpu")
-    rec = torch.zeros((len(outs), topk, RECORD_WIDTH), dtype=torch.float32, device=dev)
+    """Per-clip return dicts (with top_* keys) -> (B, topk, RECORD_WIDTH) f32 tensor, zero padded.  The sweep's inner
+    loop: no device -> host copy and no per-clip synchronisation - the host-side roi lists go up in one padded array and
+    are gathered by the top pairs on the device."""
+    B = len(outs)
+    dev = outs[0]["prd_scores"].device if B else torch.device("cpu")
+    rec = torch.zeros((B, topk, RECORD_WIDTH), dtype=torch.float32, device=dev)
+    if B == 0:
+        return rec
+    ks = np.array([min(int(d["top_scores"].shape[0]), topk) for d in outs], np.int64)
+    kmax = int(ks.max())
+    pmax = max(int(d["sbj_rois"].shape[0]) for d in outs)
+    boxes = np.zeros((B, max(pmax, 1), 8), np.float32)
     for b, d in enumerate(outs):
-        k = int(d["top_scores"].shape[0])
-        pair = d["top_pair"].cpu().numpy()
-        rec[b, :k, 0] = d["top_scores"]
-        rec[b, :k, 1] = d["top_sbj"].float()
-        rec[b, :k, 2] = d["top_prd"].float()
-        rec[b, :k, 3] = d["top_obj"].float()
-        rec[b, :k, 4:8] = torch.from_numpy(np.ascontiguousarray(d["sbj_rois"][pair, 1:5])).to(dev)
-        rec[b, :k, 8:12] = torch.from_numpy(np.ascontiguousarray(d["obj_rois"][pair, 1:5])).to(dev)
-        rec[b, :, 12] = clip_offset + b
-        rec[b, :, 13] = k
+        boxes[b, :d["sbj_rois"].shape[0], :4] = d["sbj_rois"][:, 1:5]
+        boxes[b, :d["obj_rois"].shape[0], 4:] = d["obj_rois"][:, 1:5]
+    meta = np.zeros((B, topk, 3), np.float32)                       # [valid, clip id, count]
+    meta[:, :, 0] = np.arange(topk)[None, :] < ks[:, None]
+    meta[:, :, 1] = clip_offset + np.arange(B)[:, None]
+    meta[:, :, 2] = ks[:, None]
+    boxes_d = torch.from_numpy(boxes).to(dev, non_blocking=True)
+    meta_d = torch.from_numpy(meta).to(dev, non_blocking=True)
+    if kmax:
+        pad = torch.nn.utils.rnn.pad_sequence
+
+        def col(key):
+            return pad([d[key][:topk] for d in outs], batch_first=True)
+        rec[:, :kmax, 0] = col("top_scores")
+        rec[:, :kmax, 1] = col("top_sbj").float()
+        rec[:, :kmax, 2] = col("top_prd").float()
+        rec[:, :kmax, 3] = col("top_obj").float()
+        pair = col("top_pair").long().clamp_(0, boxes.shape[1] - 1)
+        rec[:, :kmax, 4:12] = boxes_d.gather(1, pair[:, :, None].expand(-1, -1, 8))
+        rec[:, :, :12] *= meta_d[:, :, :1]
+    rec[:, :, 12:14] = meta_d[:, :, 1:]
     return rec
 
 

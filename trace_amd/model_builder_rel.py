@@ -285,7 +285,7 @@ class Generalized_RCNN(PackedLinears):
         super().__setattr__(name, value)
 
     def forward_clips(self, all_frames, blob_conv, feat_map, det_rois, im_scale=1.0, f_scale=1.0, topk=0, prd_k=1,
-                      det_labels=None, det_scores=None, pairs=None, pair_labels=None):
+                      det_labels=None, det_scores=None, pairs=None, pair_labels=None, lim_score=1.0):
         """Inference on B clips: the batched hot path behind `forward` (which keeps the reference's one-clip signature).
           all_frames (B,T,3,h,w) f32 GPU   the clip (model_builder_rel.py:688); or decoded uint8 frames (B,T,h,w,3), from
                                            which Prd_RCNN.pixel_means is subtracted inside the stem kernel
@@ -302,6 +302,8 @@ class Generalized_RCNN(PackedLinears):
                      enumerating all ordered pairs (RelPN, :906).
           pair_labels optional list of B dicts(sbj_labels, obj_labels [1-based], sbj_scores, obj_scores), one entry per
                      pair: `use_gt_labels` (:844-858) - per-pair labels / scores that also index the frequency bias.
+          lim_score  RelPN's argument of that name (relpn_heads.py:57, :94): the overlap filter is skipped below 0.015 -
+                     the detected-box branch gets there when its score threshold had to be lowered (:911-935).
         Returns a list of B dicts with the reference's return keys (:1162-1182)."""
         if self.training:
             raise ValueError('You should call this function only on inference. '
@@ -309,7 +311,7 @@ class Generalized_RCNN(PackedLinears):
         with torch.no_grad():
             dev = all_frames.device
             prep = self._host_prep(det_rois, self.Prd_RCNN.out_frames(all_frames.shape[1]), im_scale, f_scale,
-                                   det_labels, det_scores, pairs, pair_labels)
+                                   det_labels, det_scores, pairs, pair_labels, lim_score)
             if self.graph_step and self.overlap_steps and ops.IGEMM_TRACE is None:
                 return self._replay_overlap(all_frames, blob_conv, feat_map, prep, topk, prd_k)
             if self._ov_pending is not None:
@@ -435,6 +437,7 @@ class Generalized_RCNN(PackedLinears):
             blob_conv = self.Conv_Body(data)                                                     # :702
             feat_map = self.Prd_RCNN2D(all_frames[:, int(bf_cur_len)])                           # :1006-1007
             pairs = pair_labels = det_labels = det_scores = None
+            lim_score = cfg.TEST_SCORE_THRESH           # RelPN's lim_score (:906, :916): the threshold the detections passed
             bad_gt = roidb is None or (len(roidb['sbj_gt_boxes']) + len(roidb['obj_gt_boxes'])) <= 0   # :767-771
             if not bad_gt:
                 # ---- gt-box branch (:772-888).  Box_Head / S_Head / O_Head pool sbj_rois / obj_rois / det_rois there;
@@ -458,10 +461,17 @@ class Generalized_RCNN(PackedLinears):
                     det_scores = [np.amax(np.asarray(rpn_pre['score'], np.float32)[:, 1:], axis=1)]
             else:
                 # ---- detected boxes (:733, :908-935): RPN -> Box_Head / Box_Outs on every proposal -> per-class NMS
-                if self.RPN is None:
+                if rpn_pre is not None:
+                    # pre-processed rois on another dataset than VidVRD (:704-731 eval branch): they stand in for the RPN's
+                    # proposals and then go through the detection heads + NMS like proposals (:908-935)
+                    if dataset_name.find('vid') >= 0:
+                        rpn_pre['rois'][:, 1:] *= float(im_info_np[0, -1])
+                    rpn_ret = {'rois': np.asarray(rpn_pre['rois'], np.float32)}
+                elif self.RPN is None:
                     raise RuntimeError("Generalized_RCNN.forward: no gt boxes and no pre-computed boxes were given, and "
                                        "model.RPN is not set (RPN + generate_proposals: model_builder_rel.py:733)")
-                rpn_ret = self.RPN(blob_conv, im_info, roidb)
+                else:
+                    rpn_ret = self.RPN(blob_conv, im_info, roidb)
                 box_feat = self.Box_Head(blob_conv, rpn_ret, use_relu=True)                      # :742
                 cls_score, bbox_pred = self.Box_Outs(box_feat)                                   # :743
                 rois_d = torch.from_numpy(np.asarray(rpn_ret['rois'], np.float32)).to(dev)
@@ -469,6 +479,9 @@ class Generalized_RCNN(PackedLinears):
                 while score_thresh >= -1e-05:                                                    # :911-935
                     d_rois, d_lab, d_sc, _ = box_ops.prepare_det_rois(
                         rois_d, cls_score, bbox_pred, im_info_np, score_thresh, cfg.TEST_NMS, cfg.DETECTIONS_PER_IM, 1)
+                    # the reference leaves the loop when RelPN returns at least one pair (:916-920).  RelPN pairs a single
+                    # detection with itself (relpn_heads.py:79-84 removes self pairs only when there are two or more) and
+                    # its overlap filter never empties the list (:99), so that is exactly "at least one detection"
                     if d_rois.shape[0] > 0:
                         break
                     if score_thresh >= 0.02 - 1e-04:
@@ -478,11 +491,13 @@ class Generalized_RCNN(PackedLinears):
                         iter_num += 1
                     else:
                         score_thresh = -2e-06
+                lim_score = score_thresh
                 det_rois = d_rois.cpu().numpy().astype(np.float32)
                 det_labels = [d_lab.cpu().numpy().astype(np.int64)]
                 det_scores = [d_sc.cpu().numpy().astype(np.float32)]
             outs = self.forward_clips(all_frames, blob_conv, feat_map, [det_rois], im_scale=im_scale, f_scale=f_scale,
-                                      det_labels=det_labels, det_scores=det_scores, pairs=pairs, pair_labels=pair_labels)
+                                      det_labels=det_labels, det_scores=det_scores, pairs=pairs, pair_labels=pair_labels,
+                                      lim_score=lim_score)
             if outs is None:                        # overlap_steps returns the previous step: one clip per call wants its own
                 outs = self.flush_steps()
             o = outs[0]
@@ -782,7 +797,7 @@ class Generalized_RCNN(PackedLinears):
         return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
     def _host_prep(self, det_rois, Tn, im_scale, f_scale, det_labels=None, det_scores=None, pairs_in=None,
-                   pair_labels=None):
+                   pair_labels=None, lim_score=1.0):
         """Host side of a step: roi lists, box trees, pair lists (numpy, as in the reference), packed for
         one upload.  `sig` identifies every launch shape of the step."""
         cfg = self.cfg
@@ -827,7 +842,7 @@ class Generalized_RCNN(PackedLinears):
                 # RelPN (relpn_heads.py:71-105): person subjects on Action Genome, then the overlap filter on the
                 # boxes in original image scale
                 s, o = box_ops.relpn_pair_indices(n, det_labels[b] if person_sbj else None, cfg.dataset)
-                if cfg.USE_OVLP_FILTER:
+                if cfg.USE_OVLP_FILTER and lim_score >= 0.015:
                     bx = (det_all[off[b]:off[b + 1], 1:5] / np.float32(im_scale)).astype(np.float32)
                     keep = box_ops.ovlp_filter(bx[s], bx[o])
                     s, o = s[keep], o[keep]
@@ -1225,37 +1240,3 @@ class Generalized_RCNN(PackedLinears):
                 d.update({name: v[b, :k] for name, v in top.items()})
             outs.append(d)
         return outs
-
-    @staticmethod
-    def topk_triplets_batched(prd, sbj_sc, obj_sc, sbj_lab, obj_lab, pclip, poff, poff_d, topk, prd_k=1):
-        """`topk_triplets` for every clip at once: the ragged per-clip candidate lists are scattered into
-        a (B, Pmax*prd_k) matrix padded with -1 (scores are products of probabilities, >= 0) and ranked
-        by one top-k.  Returns (B, topk) tensors; clip b's first min(topk, P_b*prd_k) columns are valid."""
-        B = len(poff) - 1
-        kk = min(prd_k, prd.shape[1])
-        sc, lab = torch.topk(prd, kk, dim=1)                       # (Ptot, kk)
-        spo = (sbj_sc * obj_sc)[:, None] * sc
-        pmax = int(np.max(np.diff(poff))) if B else 0
-        local = torch.arange(prd.shape[0], device=prd.device) - poff_d[pclip]
-        dense = torch.full((B, pmax * kk), -1.0, dtype=spo.dtype, device=prd.device)
-        col = local[:, None] * kk + torch.arange(kk, device=prd.device)[None, :]
-        dense[pclip[:, None].expand(-1, kk), col] = spo
-        k = min(topk, pmax * kk)
-        top, idx = torch.topk(dense, k, dim=1)                     # ties: torch.topk order, as topk_triplets
-        pair = idx // kk + poff_d[:, None]
-        pair = pair.clamp_(max=prd.shape[0] - 1)
-        return dict(top_scores=top, top_pair=idx // kk, top_prd=lab.reshape(-1)[(pair * kk + idx % kk)],
-                    top_sbj=sbj_lab[pair], top_obj=obj_lab[pair])
-
-    @staticmethod
-    def topk_triplets(d, topk, prd_k=1):
-        """Ranking core of lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 on device: top prd_k
-        predicates per pair, score = sbj*obj*prd, global top-k -> fixed-size triplet records."""
-        prd = d["prd_scores"]
-        sc, lab = torch.topk(prd, min(prd_k, prd.shape[1]), dim=1)
-        spo = (d["sbj_scores"] * d["obj_scores"])[:, None] * sc
-        k = min(topk, spo.numel())
-        top, idx = torch.topk(spo.reshape(-1), k)
-        pair = idx // sc.shape[1]
-        return dict(top_scores=top, top_pair=pair, top_prd=lab.reshape(-1)[idx],
-                    top_sbj=d["sbj_labels"][pair], top_obj=d["obj_labels"][pair])
