@@ -131,7 +131,7 @@ def secondary_configs(dev, prd_k, steps=5, only=None, kernels=True):
         out.append(dict(workload=tag, clips_per_gpu=B, frames=T, objects=n, pairs_per_clip=pairs, prd_k=kk,
                         value=B / dt, unit="clips/sec", ms_per_step=dt * 1e3, pairs_per_sec=sum(pairs) / dt,
                         roofline_roi_align=kern["roi_align"], roofline_roi_align_avg=kern["roi_align_avg"],
-                        roofline_pair={"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"]}))
+                        roofline_pair={"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"], "mfma": kern["pair_mfma"]}))
         m.drop_graphs()
         del m
         torch.cuda.empty_cache()
@@ -344,7 +344,7 @@ def main():
         "roofline_roi_align": kern and kern["roi_align"],
         "roofline_roi_align_adaptive": kern and kern["roi_align_adaptive"],
         "roofline_roi_align_avg": kern and kern["roi_align_avg"],
-        "roofline_pair": kern and {"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"]},
+        "roofline_pair": kern and {"pool": kern["pair_pool"], "combine": kern["pair_combine"], "fused": kern["pair_infer"], "mfma": kern["pair_mfma"]},
         "roofline_nms": kern and {"rpn": kern["nms_rpn"], "per_class": kern["nms_per_class"]},
         "i3d_algorithmic_tflops": value * I3D_GFLOP_PER_CLIP / 1e3,
         "prd_k": args.prd_k, "overlap_steps": bool(args.overlap) and args.pipeline == 1, "side_stream": bool(args.side_stream),

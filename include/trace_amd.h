@@ -289,6 +289,13 @@ int trace_gemm_bf16_nt_ex(const uint16_t* A, const uint16_t* Bm, int M, int N, i
 int trace_gemm_bf16_nt_dual(const uint16_t* A, int lda, int K1, const uint16_t* A2, int lda2, int K2, const uint16_t* Bm,
                             int ldb, int M, int N, int ldc, const float* bias, const void* residual, int epilogue, void* C,
                             trace_stream_t stream);
+/* trace_gemm_bf16_nt_dual with the second output of trace_gemm_bf16_nt_ex: C2 (or NULL) = bf16(act2(C value)), same rows /
+ * ldc.  With TRACE_EPI_OUT_F32 the block's f32 residual stream and the next conv's bf16 operand leave one launch. */
+int trace_gemm_bf16_nt_dual_ex(const uint16_t* A, int lda, int K1, const uint16_t* A2, int lda2, int K2,
+                               const uint16_t* Bm, int ldb, int M, int N, int ldc, const float* bias,
+                               const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
+                               trace_stream_t stream);
+
 
 /* Launch-configuration override for the three entry points above, for the calling thread:
  * tile 1..9 = (64x64, 64 couts x 128 positions, 128 x 64, 128x128, 128 x 256, 256 x 128, 256x256, 128 x 192,
@@ -368,6 +375,21 @@ int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, int D, cons
                            const float* rel_rois, const int32_t* sbj_inds, const int32_t* obj_inds,
                            const int32_t* partner, int P, const float* bias, float spatial_scale, int pooled,
                            uint16_t* sp, trace_stream_t stream);
+
+/* trace_pair_infer_fused on the matrix cores (same references, same arguments where they share a name): the union-box
+ * pooling as a matrix product  pooled[ch][cell] = sum_pix mapT[ch][pix] * Wt[pix][cell]  on v_mfma_f32_16x16x32_bf16,
+ * scores, softmax over the cells and the combine in the epilogue, one workgroup per union box.
+ *   vabT (B, 3D, ldp) bf16: [V | W_A V | W_B V] CHANNEL-major, pixel axis (y * W + x) contiguous with pitch ldp = 224,
+ *     columns H*W .. ldp-1 zero, computed WITHOUT its bias;  vbias (3D) f32 (or NULL): that bias, added as
+ *     vbias[ch] * (sum of the cell's weights);  maps of at most 16 x 16 pixels with H*W <= 200, pooled <= 8, D % 32 == 0.
+ *   work (n_work x 12 int32, 16-byte aligned) or NULL: one record per union box to pool - [pair p, its swapped pair q or
+ *     -1, sbj_inds[p], obj_inds[p], the box's five floats (bit patterns), 3 words of padding] - so that a workgroup reads
+ *     everything it needs in one access and none is launched for the swapped pairs (with NULL: one workgroup per pair,
+ *     inputs looked up through rel_rois / sbj_inds / obj_inds / partner as in trace_pair_infer_fused). */
+int trace_pair_infer_mfma(const uint16_t* vabT, int B, int H, int W, int D, int ldp, const float* vbias,
+                          const float* qk, int ld_qk, const float* rel_rois, const int32_t* sbj_inds,
+                          const int32_t* obj_inds, const int32_t* partner, int P, const int32_t* work, int n_work,
+                          const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream);
 
 /* trace_pair_infer_fused as two launches (same references): trace_pair_pool writes the union-box pooling of
  * vab, out (P, PH*PW, 3D) bf16 = [Vp | (W_A V)p | (W_B V)p] - it needs only the 2-D map and the pair boxes, so a

@@ -101,6 +101,7 @@ def hip_stages(m, frames):
         for i, name in enumerate(r.res_layers[:r.num_stages]):
             blocks = list(getattr(r, name))
             for bi, blk in enumerate(blocks):
+                blk.res_f32 = i in r.res_f32_stages
                 x = blk.run(x, pool_t2=(i == 0 and r.with_pool2 and bi == len(blocks) - 1))
             out[name] = x
     return {k: v.float().permute(0, 4, 1, 2, 3).cpu() for k, v in out.items()}

@@ -188,6 +188,81 @@ def test_pair_infer_fused_vs_reference_order():
     assert torch.equal(sp3, sp2)
 
 
+def test_pair_infer_mfma_vs_reference_order():
+    """The matrix-core pair kernel (ops.pair_infer_mfma: channel-major maps, union-box pooling as an MFMA product, scores /
+    softmax / combine in the epilogue) against the reference's order of operations in fp32 (as the test above) and
+    against the VALU kernel; map bias through the kernel's bias x weight-sum term; swapped pairs; ragged clips."""
+    from trace_amd import ops
+    from trace_amd.model_builder_rel import swapped_pair_index
+    from oracle import c_oracle, np_oracle
+    rng = np.random.default_rng(17)
+    g = torch.Generator().manual_seed(17)
+    B, H, W, D, C = 3, 14, 14, 256, 512
+    ns = (8, 5, 1)
+    fmap = torch.randn((B, H, W, C), generator=g).bfloat16()
+    kmap = torch.randn((B, H, W, D), generator=g).bfloat16()
+    wv = (torch.randn((D, C), generator=g) / C ** 0.5)
+    wa = torch.randn((D, D), generator=g) / 16.0
+    wb = torch.randn((D, D), generator=g) / 16.0
+    bv = torch.randn((D,), generator=g) * 0.3
+    bias = torch.randn((D,), generator=g) * 0.1
+    w_vab = torch.cat([wv, wa @ wv, wb @ wv], 0).bfloat16()
+    b_vab = torch.cat([bv, wa @ bv, wb @ bv], 0)
+    nobj = sum(ns)
+    q = (torch.randn((nobj, 2, D), generator=g) * 0.2).bfloat16()
+    rois, X, Y, off = [], [], [], 0
+    for b, n in enumerate(ns):
+        r = np.concatenate([np.full((n, 1), b, np.float32), synth_boxes(rng, n)], 1)
+        if b == 0:
+            r[0, 1:] = [0, 0, 223, 223]            # a box over the whole map: every pixel row, K = 196
+            r[1, 1:] = [200, 210, 223, 223]        # a one-cell box at the border
+        s, o, rel = np_oracle.relpn_pairs(r)
+        rois.append(rel.astype(np.float32)); X.append(s + off); Y.append(o + off)
+        off += n
+    rel = np.concatenate(rois); X = np.concatenate(X); Y = np.concatenate(Y)
+    P = rel.shape[0]
+    part = torch.from_numpy(swapped_pair_index(X, Y)).to(DEV)
+    rel_d, Xd, Yd = torch.from_numpy(rel).to(DEV), torch.from_numpy(X).int().to(DEV), torch.from_numpy(Y).int().to(DEV)
+    qk = ops.gemm_nt(q.view(2 * nobj, D).to(DEV), kmap.view(-1, D).to(DEV), out_f32=True)
+    assert ops.pair_mfma_supported(H, W, 7, D)
+    vabT = ops.pair_maps_channel_major(fmap.to(DEV), w_vab.to(DEV))
+    assert tuple(vabT.shape) == (B, 3 * D, 224) and float(vabT[:, :, H * W:].abs().max()) == 0.0
+    sp = ops.pair_infer_mfma(vabT, (H, W), b_vab.to(DEV), qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7, partner=part)
+    sp_np = ops.pair_infer_mfma(vabT, (H, W), b_vab.to(DEV), qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7)
+    assert torch.equal(sp, sp_np)                                    # swapped pairs pooled once: same rows
+    # the work list (one record per union box, no workgroup for the swapped pairs): same rows again
+    rec = ops.pair_work_records(X, Y, rel, part.cpu().numpy())
+    assert rec.shape == (int(((part.cpu().numpy() < 0) | (part.cpu().numpy() > np.arange(P))).sum()), 12)
+    sp_w = ops.pair_infer_mfma(vabT, (H, W), b_vab.to(DEV), qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7, partner=part,
+                               work=torch.from_numpy(rec).to(DEV))
+    assert torch.equal(sp_w, sp)
+    rec_all = ops.pair_work_records(X, Y, rel, None)
+    assert rec_all.shape[0] == P
+    assert torch.equal(ops.pair_infer_mfma(vabT, (H, W), b_vab.to(DEV), qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7,
+                                           work=torch.from_numpy(rec_all).to(DEV)), sp)
+    for _ in range(3):
+        assert torch.equal(ops.pair_infer_mfma(vabT, (H, W), b_vab.to(DEV), qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7, partner=part), sp)
+    # the VALU kernel on the channels-last maps (bias inside the maps)
+    vab = ops.gemm_nt(fmap.view(-1, C).to(DEV), w_vab.to(DEV), bias=b_vab.to(DEV)).view(B, H, W, 3 * D)
+    sp_valu = ops.pair_infer(vab, qk, rel_d, Xd, Yd, bias.to(DEV), 1 / 16., 7, partner=part)
+    d = (sp.float() - sp_valu.float())
+    assert float(d.norm() / sp_valu.float().norm()) < 1e-2
+    # the reference's order of operations in fp32, from the same bf16 maps
+    vmaps = vab.float().cpu()
+    kp = torch.from_numpy(c_oracle.roi_align_fwd(kmap.float().permute(0, 3, 1, 2).contiguous().numpy(), rel, 1 / 16., 7, 7, 0))
+    pooled = [torch.from_numpy(c_oracle.roi_align_fwd(vmaps[..., i * D:(i + 1) * D].permute(0, 3, 1, 2).contiguous().numpy(),
+                                                      rel, 1 / 16., 7, 7, 0)) for i in range(3)]
+    att = []
+    for col, idx in ((0, X), (1, Y)):
+        score = (q[idx, col].float().view(P, D, 1, 1) * kp).sum(1).view(P, -1)
+        att.append(F.softmax(score, 1).view(P, 1, 7, 7))
+    ref = F.leaky_relu(att[0] * pooled[1] + att[1] * pooled[2] + bias.view(1, D, 1, 1), 0.1) + pooled[0]
+    got = sp.float().cpu().view(P, 49, D).permute(0, 2, 1).reshape(P, D, 7, 7)
+    err = float((got - ref).norm() / ref.norm())
+    assert err < 1e-2, err
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
 def test_pair_kernels_are_deterministic_beside_lds_dma_kernels():
     """The overlapped step runs the pair kernels on a branch beside the next backbone.  A trial version of them
     (round 2: conditional pixel loads) gave run-to-run different rows ONLY while a kernel that fills LDS by LDS-DMA
@@ -217,6 +292,9 @@ def test_pair_kernels_are_deterministic_beside_lds_dma_kernels():
     wt = (torch.randn((512, 3 * 512), generator=g) * 0.02).bfloat16().to(DEV)
     ref_sp = ops.pair_infer(vab, qk, rel, Xd, Yd, bias, 1 / 16., 7, partner=part)
     ref_pool = ops.pair_pool(vab, rel, 1 / 16., 7, partner=part)
+    vabT = torch.zeros((B, 3 * D, 224), dtype=torch.bfloat16, device=DEV)
+    vabT[:, :, :H * W] = vab.view(B, H * W, 3 * D).permute(0, 2, 1)
+    ref_mfma = ops.pair_infer_mfma(vabT, (H, W), None, qk, rel, Xd, Yd, bias, 1 / 16., 7, partner=part)
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     bad = 0
@@ -227,9 +305,10 @@ def test_pair_kernels_are_deterministic_beside_lds_dma_kernels():
                 ops.conv3d(xc, wt, None, (3, 1, 1), (1, 1, 1), (1, 0, 0), relu=True)
         sp = ops.pair_infer(vab, qk, rel, Xd, Yd, bias, 1 / 16., 7, partner=part)
         pooled = ops.pair_pool(vab, rel, 1 / 16., 7, partner=part)
-        bad += int(not torch.equal(sp, ref_sp)) + int(not torch.equal(pooled[lead], ref_pool[lead]))
+        spm = ops.pair_infer_mfma(vabT, (H, W), None, qk, rel, Xd, Yd, bias, 1 / 16., 7, partner=part)
+        bad += int(not torch.equal(sp, ref_sp)) + int(not torch.equal(pooled[lead], ref_pool[lead])) + int(not torch.equal(spm, ref_mfma))
     torch.cuda.synchronize()
-    assert bad == 0, "%d of 80 launches differ from the solo result" % bad
+    assert bad == 0, "%d of 120 launches differ from the solo result" % bad
 
 
 @pytest.mark.parametrize("prd_k,topk,big", [(1, 100, 0), (3, 100, 0), (20, 50, 0), (200, 7, 0), (2, 100, 9900), (20, 100, 9900),

@@ -101,6 +101,12 @@ def measure(dev, B=8, n=20, Tn=4, C=2048, fm=14, seed=1, nms=True):
     fused_bytes = P * 49 * D * 2 + vab.numel() * 2 + P * 49 * 2 * 4 * 4
     out["pair_infer"] = entry("trace::pair_infer_kernel", timed(lambda: ops.pair_infer(vab, qk, und, Xd, Yd, bias, 1 / 16., 7, partner=part)),
                               fused_bytes, pairs=P, D=D, call="pool + combine in one launch (no pooled map in HBM)")
+    vabT = torch.zeros((B, 3 * D, 224), dtype=torch.bfloat16, device=dev)
+    vabT[:, :, :fm * fm] = vab.view(B, fm * fm, 3 * D).permute(0, 2, 1)
+    vbias = torch.randn((3 * D,), device=dev)
+    work = torch.from_numpy(ops.pair_work_records(X, Y, un, part.cpu().numpy())).to(dev)
+    out["pair_mfma"] = entry("trace::pair_mfma_kernel", timed(lambda: ops.pair_infer_mfma(vabT, (fm, fm), vbias, qk, und, Xd, Yd, bias, 1 / 16., 7, partner=part, work=work)),
+                             fused_bytes, pairs=P, D=D, call="pool (MFMA) + combine in one launch, channel-major maps")
     if not nms:
         return out
     # NMS: SURVEY 8d stress sizes.  Algorithmic bytes = N*20 in + N*8 out (compute-light: boxes/s is the figure)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "trace_conv3d_igemm_bf16": (c_int, [P] + [c_int] * 5 + [P, P] + [c_int] * 13 + [P, c_int, P, P, c_size_t, P]),
     "trace_maxpool3d_ndhwc_bf16": (c_int, [P] + [c_int] * 14 + [P, P]),
     "trace_gemm_bf16_nt_dual": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P]),
+    "trace_gemm_bf16_nt_dual_ex": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, P, c_int, P, P, c_int, P]),
     "trace_gemm_bf16_nt_ex": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, c_longlong, P, c_int, P, P, c_int, P, c_size_t, P]),
     "trace_gemm_bf16_nt": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_longlong, c_longlong, c_float, P, P, c_int, P, P, c_size_t, P]),
     "trace_igemm_tune": (c_int, [c_int, c_int, c_int]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     "trace_pair_attention_fused": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P, c_float, c_int, c_int, P, P, P, P]),
     "trace_upload_slots": (c_int, [P, c_size_t, P, P, c_size_t, P]),
     "trace_pair_infer_fused": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, c_float, c_int, P, P]),
+    "trace_pair_infer_mfma": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, P, P, P, c_int, P, c_int, P, c_float, c_int, P, P]),
     "trace_pair_pool": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_int, c_float, c_int, P, P]),
     "trace_pair_combine": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, c_float, c_int, P, P]),
     "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,

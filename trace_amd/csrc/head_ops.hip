@@ -567,6 +567,292 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Pair attention as MFMA tiles (model_builder_rel.py:1524-1612, :1039-1041; the arithmetic of pair_infer_kernel).
+// The union-box pooling of a map is a small matrix product over the map's pixels,
+//     pooled[ch][cell] = sum_pix mapT[ch][pix] * Wt[pix][cell],   Wt[(y,x)][(cy,cx)] = wy[cy][y] * wx[cx][x]
+// (wy / wx: the bilinear weights of the cell's samples along one axis, summed and divided by the sample count; a
+// sample is dropped iff its y OR its x is out of range, so the product form is exact), and one workgroup computes it for
+// all 3 D channels of [V | W_A V | W_B V] of one union box on v_mfma_f32_16x16x32_bf16:
+//   * the maps arrive CHANNEL-major, vabT (B, 3D, ldp) bf16 with the pixel axis contiguous (the producing GEMM simply
+//     runs transposed), so the A operand (rows = channels, K = pixels) is a 16-byte global load per lane - no LDS
+//     staging, no transpose.  K runs over the box's pixel ROWS (y0 W .. (y1 + 1) W, from an 8-aligned start);
+//   * the B operand is the weight image Wt (bf16, [64 cells][K]) built in LDS from the two 7 x 14 axis tables;
+//   * scores of the scalar maps q.K (f32, from the same axis tables), softmax over the cells, and the combine
+//     sp = LeakyReLU(a_s VAp + a_o VBp + b) + Vp run on the accumulators; the map GEMM's bias enters as
+//     bias[ch] * (sum of the cell's weights) - the pooled value of a constant map;
+//   * the swapped pair (same union box) is written from the same accumulators.
+// Eight waves: wave w owns channels 32 w .. 32 w + 31 of each of the three maps (rows permuted so that a lane ends up
+// with 8 consecutive channels of a cell -> 16-byte stores) and all 64 cell columns: 24 accumulator tiles.
+// ---------------------------------------------------------------------------
+constexpr int PM_LDP = 224;        // pixel pitch of vabT (>= H * W rounded up to 8, + 24)
+constexpr int PM_WROW = PM_LDP + 8;  // weight image row (elements): 464 B, rows 16 B apart mod 128 B
+constexpr int PM_THREADS = 256;
+typedef __attribute__((ext_vector_type(8))) short pm_s8;
+typedef __attribute__((ext_vector_type(4))) float pm_f4;
+
+__global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
+    const uint16_t* __restrict__ vabT, int B, int H, int W, int D, const float* __restrict__ vbias,
+    const float* __restrict__ qk, int ld_qk, const float* __restrict__ rel_rois, const int32_t* __restrict__ sbj,
+    const int32_t* __restrict__ obj, const int32_t* __restrict__ partner, const int32_t* __restrict__ work,
+    const float* __restrict__ bias_ab, float scale, int PS, uint16_t* __restrict__ sp) {
+  __shared__ __attribute__((aligned(16))) uint16_t wimg[64 * PM_WROW];
+  __shared__ float wy[8][16], wx[8][16], sy[8], sx[8];
+  __shared__ int ylo[8], yhi[8];
+  __shared__ float qrow[4][PM_LDP];
+  __shared__ float rsc[4][16][8];      // x-pooled scalar maps: [which][y][cx]
+  __shared__ float prob[4][64];        // pooled scores, then softmax weights: [2 pair + (s | o)][cell]
+  __shared__ unsigned char chy[PM_LDP / 8], chx[PM_LDP / 8];   // (y, x) of the first pixel of every 8-pixel chunk
+  __shared__ __attribute__((aligned(16))) float bias_l[4][512];   // map bias of V | W_A V | W_B V, then b_A + b_B  (D <= 512)
+  const int tid = threadIdx.x;
+  const int cells = PS * PS;
+  const int HW = H * W;
+  // One workgroup per union box.  With `work` (12 words per box: pair p, swapped pair q or -1, subject and object of p,
+  // the box, padding) everything the box needs arrives in one 48-byte read and no workgroup is launched for the swapped
+  // pairs; without it a workgroup per pair looks its inputs up and the higher index of a swapped pair exits.
+  int p, q, s_i, o_i;
+  float roi[5];
+  if (work) {
+    const int4 w0 = *reinterpret_cast<const int4*>(work + 12 * (long long)blockIdx.x);
+    const float4 w1 = *reinterpret_cast<const float4*>(work + 12 * (long long)blockIdx.x + 4);
+    p = w0.x; q = w0.y; s_i = w0.z; o_i = w0.w;
+    roi[0] = w1.x; roi[1] = w1.y; roi[2] = w1.z; roi[3] = w1.w;
+    roi[4] = __int_as_float(work[12 * (long long)blockIdx.x + 8]);
+  } else {
+    p = blockIdx.x;
+    q = partner ? partner[p] : -1;
+    if (q >= 0 && q < p) return;
+    s_i = sbj[p];
+    o_i = obj[p];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) roi[i] = rel_rois[(long long)p * 5 + i];
+  }
+  const int npair = q > p ? 2 : 1;
+
+  PGeom g;
+  pa_geometry(roi, B, scale, PS, g);
+  // ---- axis tables: thread (axis, bin) walks its samples (model_builder_rel.py:1566-1569 -> ROIAlign_cuda.cu:64-122)
+  if (tid < 2 * PS) {
+    const int axis = tid >= PS, b = axis ? tid - PS : tid;
+    const float start = axis ? g.start_w : g.start_h, bin = axis ? g.bin_w : g.bin_h;
+    const int grid = axis ? g.grid_w : g.grid_h, dim = axis ? W : H;
+    float* row = axis ? wx[b] : wy[b];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) row[i] = 0.f;
+    const float inv = 1.0f / (float)grid;
+    float tot = 0.f;
+    int first = 16, last = -1;
+    for (int i = 0; i < grid; ++i) {
+      float c = start + (float)b * bin + ((float)i + .5f) * bin / (float)grid;
+      if (c < -1.0f || c > (float)dim) continue;
+      if (c <= 0.f) c = 0.f;
+      int lo = (int)c, hi;
+      if (lo >= dim - 1) { hi = lo = dim - 1; c = (float)lo; } else { hi = lo + 1; }
+      const float l = c - (float)lo, h = 1.f - l;
+      row[lo] += h * inv;
+      row[hi] += l * inv;
+      tot += inv;
+      first = min(first, lo);
+      last = max(last, hi);
+    }
+    (axis ? sx : sy)[b] = tot;
+    if (!axis) {
+      ylo[b] = first;
+      yhi[b] = last;
+    }
+  }
+  for (int i = tid; i < 4 * D; i += PM_THREADS) {
+    const int mt = i / D, c = i - mt * D;
+    bias_l[mt][c] = mt < 3 ? (vbias ? vbias[i] : 0.f) : bias_ab[c];
+  }
+  if (tid < PM_LDP / 8) {
+    const int y = (8 * tid) / W;
+    chy[tid] = (unsigned char)min(y, 15);
+    chx[tid] = (unsigned char)(8 * tid - y * W);
+  }
+  // ---- the queries' scalar maps of this clip (rows 2 i = q_s of object i, 2 i + 1 = q_o), zero behind the map
+  {
+    const int which = tid >> 6, l = tid & 63;
+    if (which < 2 * npair) {
+      // the swapped pair's subject is this pair's object and vice versa
+      const int rowi = (which & 1) ? 2 * ((which >> 1) ? s_i : o_i) + 1 : 2 * ((which >> 1) ? o_i : s_i);
+      const float* src = qk + (long long)rowi * ld_qk + (long long)g.batch * HW;
+#pragma unroll
+      for (int i = 0; i < (PM_LDP + 63) / 64; ++i) {
+        const int px = l + 64 * i;
+        if (px < PM_LDP) qrow[which][px] = px < HW ? src[px] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pixel rows the cells touch (uniform)
+  int ymin = 16, ymax = -1;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+    if (b < PS) {
+      ymin = min(ymin, ylo[b]);
+      ymax = max(ymax, yhi[b]);
+    }
+  const int k0 = ymax < 0 ? 0 : ((ymin * W) & ~7);
+  const int ksteps = ymax < 0 ? 0 : ((ymax + 1) * W - k0 + 31) >> 5;
+  // ---- scores, stage 1: the scalar maps pooled along x, items (which, y, cx)
+  for (int it = tid; it < 4 * 16 * 8; it += PM_THREADS) {
+    const int which = it >> 7, y = (it >> 3) & 15, cx = it & 7;
+    float r = 0.f;
+    if (which < 2 * npair && y < H && cx < PS) {
+      const float* qr = &qrow[which][y * W];
+#pragma unroll
+      for (int x = 0; x < 16; ++x) r += wx[cx][x] * qr[x];      // wx is 0 from x = W on; qr stays inside the zero-filled row
+    }
+    rsc[which][y][cx] = r;
+  }
+  // ---- weight image: [cell][k0 + 32 ksteps) bf16, eight pixels per item
+  {
+    const int chunks = ksteps * 4;
+    const int cbase = k0 >> 3;
+    const int cell = tid & 63;
+    const int cy = cell / PS, cx = cell - cy * PS;
+    for (int c8 = tid >> 6; c8 < chunks; c8 += PM_THREADS / 64) {
+      uint4 o = make_uint4(0, 0, 0, 0);
+      if (cell < cells) {
+        int y = chy[cbase + c8], x = chx[cbase + c8];
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          w8[j] = y < H ? wy[cy][y] * wx[cx][x] : 0.f;
+          if (++x == W) {
+            x = 0;
+            ++y;
+          }
+        }
+        o.x = pack_bf16x2(w8[0], w8[1]);
+        o.y = pack_bf16x2(w8[2], w8[3]);
+        o.z = pack_bf16x2(w8[4], w8[5]);
+        o.w = pack_bf16x2(w8[6], w8[7]);
+      }
+      *reinterpret_cast<uint4*>(&wimg[cell * PM_WROW + 8 * c8]) = o;
+    }
+  }
+  __syncthreads();
+  // ---- scores, stage 2 (along y) and the softmax over the cells: wave `which`, lane = cell
+  {
+    const int which = tid >> 6, cell = tid & 63;
+    if (which < 2 * npair) {
+      float a = -__builtin_inff();
+      if (cell < cells) {
+        const int cy = cell / PS, cx = cell - cy * PS;
+        a = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) a += wy[cy][y] * rsc[which][y][cx];
+      }
+      float mx = a;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      const float e = cell < cells ? expf(a - mx) : 0.f;
+      float ss = e;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+      prob[which][cell] = e / ss;
+    }
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  for (int cb = wave * 32; cb < D; cb += (PM_THREADS / 64) * 32) {
+    // A rows: tile t of the wave's pair of 16-row tiles holds channels cb + 8 (m >> 2) + 4 t + (m & 3), m = li
+    const uint16_t* arow[3][2];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ch = cb + 8 * (li >> 2) + 4 * t + (li & 3);
+        arow[mt][t] = vabT + ((long long)(g.batch * 3 + mt) * D + ch) * PM_LDP + k0 + 8 * kg;
+      }
+    pm_f4 acc[3][2][4];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) acc[mt][t][nf] = pm_f4{0.f, 0.f, 0.f, 0.f};
+    // the NEXT K-step's fragments are loaded before this step's 24 MFMAs (two register sets): an L2 round trip hides
+    // behind the matrix work of this wave and of the other workgroup on the CU
+    pm_s8 af[2][3][2];
+    auto load_step = [&](int set, int ks) {
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) af[set][mt][t] = *reinterpret_cast<const pm_s8*>(arow[mt][t] + 32 * ks);
+    };
+    auto mma_step = [&](int set, int ks) {
+      pm_s8 bf[4];
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+        bf[nf] = *reinterpret_cast<const pm_s8*>(&wimg[(16 * nf + li) * PM_WROW + 32 * ks + 8 * kg]);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[mt][t][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mt][t], bf[nf], acc[mt][t][nf], 0, 0, 0);
+    };
+    if (ksteps > 0) load_step(0, 0);
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      if (ks + 1 < ksteps) load_step(1, ks + 1);
+      mma_step(0, ks);
+      if (ks + 1 < ksteps) {
+        if (ks + 2 < ksteps) load_step(0, ks + 2);
+        mma_step(1, ks + 1);
+      }
+    }
+    // ---- combine: the lane holds channels c .. c + 7 (rows 4 kg + r of tiles t = 0, 1) of cell 16 nf + li
+    const int c = cb + 8 * kg;
+    float vb[3][8], bab[8];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[mt][j] = bias_l[mt][c + j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bab[j] = bias_l[3][c + j];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int cell = 16 * nf + li;
+      if (cell >= cells) continue;
+      const int cy = cell / PS, cx = cell - cy * PS;
+      const float wsum = sy[cy] * sx[cx];
+      float v[8], a[8], b[8];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[4 * t + r] = acc[0][t][nf][r] + vb[0][4 * t + r] * wsum;
+          a[4 * t + r] = acc[1][t][nf][r] + vb[1][4 * t + r] * wsum;
+          b[4 * t + r] = acc[2][t][nf][r] + vb[2][4 * t + r] * wsum;
+        }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (k >= npair) break;
+        const float ws = prob[2 * k][cell], wo = prob[2 * k + 1][cell];
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = ws * a[j] + wo * b[j] + bab[j];       // A(s_map) + B(o_map)  (:1039)
+          t = t > 0.f ? t : 0.1f * t;                     // LeakyReLU(0.1)
+          o[j] = t + v[j];                                // + V  (:1040)
+        }
+        uint4 pk;
+        pk.x = pack_bf16x2(o[0], o[1]);
+        pk.y = pack_bf16x2(o[2], o[3]);
+        pk.z = pack_bf16x2(o[4], o[5]);
+        pk.w = pack_bf16x2(o[6], o[7]);
+        *reinterpret_cast<uint4*>(sp + ((long long)(k ? q : p) * cells + cell) * D + c) = pk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Tree-GRU: one workgroup per (tree, feature group); levels are walked inside
 // the kernel (a tree is independent of every other tree), so the whole
 // bottom-up + top-down pass of all clips and groups is ONE launch.
@@ -1179,6 +1465,27 @@ extern "C" int trace_pair_infer_fused(const uint16_t* vab, int B, int H, int W, 
   hipLaunchKernelGGL(pair_infer_kernel, dim3(P), dim3(256), 0, (hipStream_t)stream, vab, B, H, W, D, qk, ld_qk, rel_rois,
                      sbj_inds, obj_inds, partner, bias, spatial_scale, pooled, sp);
   return check_launch("pair_infer_fused");
+}
+
+extern "C" int trace_pair_infer_mfma(const uint16_t* vabT, int B, int H, int W, int D, int ldp, const float* vbias,
+                                     const float* qk, int ld_qk, const float* rel_rois, const int32_t* sbj_inds,
+                                     const int32_t* obj_inds, const int32_t* partner, int P, const int32_t* work, int n_work,
+                                     const float* bias, float spatial_scale, int pooled, uint16_t* sp, trace_stream_t stream) {
+  TRACE_REQUIRE(B > 0 && H > 0 && W > 0 && P >= 0 && pooled > 0, "pair_infer_mfma: bad shape");
+  TRACE_REQUIRE(D % 32 == 0 && D <= 512, "pair_infer_mfma: D=%d must be a multiple of 32, at most 512", D);
+  TRACE_REQUIRE(pooled <= 8 && H <= 16 && W <= 16, "pair_infer_mfma: needs pooled <= 8 and a map of at most 16 x 16 (got %d, %d x %d)",
+                pooled, H, W);
+  TRACE_REQUIRE(ldp == PM_LDP && (H * W + 7) / 8 * 8 + 24 <= PM_LDP, "pair_infer_mfma: pixel pitch must be %d and hold H*W + 31 pixels", PM_LDP);
+  TRACE_REQUIRE(ld_qk >= B * H * W, "pair_infer_mfma: ld_qk=%d smaller than B*H*W", ld_qk);
+  if (P == 0) return 0;
+  TRACE_REQUIRE(vabT && qk && bias && sp && (work || (rel_rois && sbj_inds && obj_inds)), "pair_infer_mfma: null pointer");
+  TRACE_REQUIRE((((uintptr_t)vabT | (uintptr_t)sp | (uintptr_t)work) & 15) == 0, "pair_infer_mfma: vabT / sp / work must be 16-byte aligned");
+  TRACE_REQUIRE(!work || (n_work >= 0 && n_work <= P), "pair_infer_mfma: bad work list");
+  const int nwg = work ? n_work : P;
+  if (nwg == 0) return 0;
+  hipLaunchKernelGGL(pair_mfma_kernel, dim3(nwg), dim3(PM_THREADS), 0, (hipStream_t)stream, vabT, B, H, W, D, vbias, qk, ld_qk, rel_rois,
+                     sbj_inds, obj_inds, partner, work, bias, spatial_scale, pooled, sp);
+  return check_launch("pair_infer_mfma");
 }
 
 extern "C" int trace_pair_pool(const uint16_t* vab, int B, int H, int W, int D, const float* rel_rois,

@@ -2272,3 +2272,12 @@ extern "C" int trace_gemm_bf16_nt_dual(const uint16_t* A, int lda, int K1, const
   return gemm_impl(A, Bm, M, N, K1 + K2, lda, ldb, ldc, 1, 0, 0, 0, 1.0f, bias, 0, residual, epilogue, C, nullptr, 0, nullptr, 0,
                    stream, A2, lda2, K1);
 }
+
+extern "C" int trace_gemm_bf16_nt_dual_ex(const uint16_t* A, int lda, int K1, const uint16_t* A2, int lda2, int K2,
+                                          const uint16_t* Bm, int ldb, int M, int N, int ldc, const float* bias,
+                                          const void* residual, int epilogue, void* C, uint16_t* C2, int epilogue2,
+                                          trace_stream_t stream) {
+  TRACE_REQUIRE(A2 && K1 > 0 && K2 > 0, "gemm_dual: bad shape");
+  return gemm_impl(A, Bm, M, N, K1 + K2, lda, ldb, ldc, 1, 0, 0, 0, 1.0f, bias, 0, residual, epilogue, C, C2, epilogue2, nullptr, 0,
+                   stream, A2, lda2, K1);
+}

@@ -212,6 +212,9 @@ class Generalized_RCNN(PackedLinears):
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
+        # ... and that kernel on the matrix cores (ops.pair_infer_mfma: union-box pooling as a matrix product, scores /
+        # softmax / combine in its epilogue) whenever the 2-D map is small enough (<= 16 x 16: TRACE's 14 x 14 maps)
+        self.pair_mfma = True
         self.share_swapped_pairs = True  # (s,o) and (o,s) have one union box: pooled once for both
         # with side_stream: the union-box pooling of the pair kernel as its own launch on the second stream, only the
         # query-dependent combine after the tree-GRU.  "tail": pooled beside the post-backbone chain (temporal object
@@ -534,7 +537,8 @@ class Generalized_RCNN(PackedLinears):
         dev = all_frames.device
         key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
-               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
+               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage,
+               self.pair_mfma)
         depth = max(1, int(self.pipeline))
         ents = self._step_graphs.get(key)
         if ents is None:
@@ -624,7 +628,8 @@ class Generalized_RCNN(PackedLinears):
         dev = all_frames.device
         key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
-               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage)
+               self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage,
+               self.pair_mfma)
         flushed = None
         if self._ov_pending is not None and self._ov_pending["key"] != key:
             flushed = self.flush_steps()          # another step signature: no graph holds that pair of steps
@@ -878,6 +883,9 @@ class Generalized_RCNN(PackedLinears):
                   reg=upl.add(np.concatenate(reg_rois, 0)),
                   pclip=upl.add(np.repeat(np.arange(B), np.diff(poff)).astype(np.int64)),
                   poff=upl.add(poff.astype(np.int64)))
+        ix["PWORK"] = upl.add(ops.pair_work_records(upl.items[ix["X32"]][1], upl.items[ix["Y32"]][1], upl.items[ix["union"]][1],
+                                                    upl.items[ix["PART32"]][1] if self.share_swapped_pairs else None))
+        n_work = int(upl.items[ix["PWORK"]][1].shape[0])
         if det_labels is not None:
             lab = np.concatenate([np.asarray(l).reshape(-1) for l in det_labels]).astype(np.int64)
             sc = np.concatenate([np.asarray(v).reshape(-1) for v in det_scores]).astype(np.float32)
@@ -896,7 +904,7 @@ class Generalized_RCNN(PackedLinears):
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=Ntot, Mtot=Mtot,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
                     sig=(Tn, tuple(n_list), tuple(m_list), tuple(len(p[0]) for p in pairs), det_labels is not None,
-                         pair_labels is not None),
+                         pair_labels is not None, n_work),
                     max_tree_nodes=max(n + m for n, m in zip(n_list, m_list)))
 
     def _host_prep_same_n(self, det_all, B, n, Tn, scale3d, off):
@@ -956,11 +964,14 @@ class Generalized_RCNN(PackedLinears):
                   union=upl.add(union.reshape(-1, 5)), t_obj=upl.add(t_obj), t_reg=upl.add(t_reg),
                   reg=upl.add(reg.reshape(-1, 5)),
                   pclip=upl.add(np.repeat(np.arange(B), P).astype(np.int64)), poff=upl.add(poff))
+        ix["PWORK"] = upl.add(ops.pair_work_records(upl.items[ix["X32"]][1], upl.items[ix["Y32"]][1], upl.items[ix["union"]][1],
+                                                    upl.items[ix["PART32"]][1] if self.share_swapped_pairs else None))
+        n_work = int(upl.items[ix["PWORK"]][1].shape[0])
         pairs = [(sidx, oidx, None, None)] * B
         n_list = [n] * B
         return dict(B=B, Tn=Tn, n_list=n_list, m_list=m_list, off=off, moff=moff, poff=poff, Ntot=B * n, Mtot=B * m,
                     det_all=det_all, pairs=pairs, upl=upl, ix=ix, forest_keys=forest_keys, forest_ix=forest_ix,
-                    sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False, False), max_tree_nodes=n + m)
+                    sig=(Tn, tuple(n_list), tuple(m_list), (P,) * B, False, False, n_work), max_tree_nodes=n + m)
 
     def _device_forward(self, all_frames, blob, fmap, prep, dv, topk, prd_k, graph_backbone, phase="all", hand=None):
         """Device side of a step: launches only (no host synchronisation, no host->device copies), so the
@@ -1045,13 +1056,19 @@ class Generalized_RCNN(PackedLinears):
                         return w, b, bab
                     w_vab, b_vab, bias_ab = self._cached("vab", make_vab, self._layer_deps(
                         [self.spatio_atten_map, self.spatio_inferA[0], self.spatio_inferB[0]]))
-                    vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
                     vmap = None
+                    if self.pair_mfma and ops.pair_mfma_supported(fmap.shape[1], fmap.shape[2], ps, low):
+                        # matrix-core pair kernel: it reads the maps channel-major (the same GEMM run transposed, its bias
+                        # applied inside the kernel) and needs no pooled intermediate
+                        vab = None
+                        pa["vabT"], pa["b_vab"] = ops.pair_maps_channel_major(fmap, w_vab), b_vab
+                    else:
+                        vab = ops.gemm_nt(fm2, w_vab, bias=b_vab).view(B, fmap.shape[1], fmap.shape[2], 3 * low)
                     # with the second stream the union-box pooling (the heavy half of the pair kernel) runs here,
                     # beside the backbone; what depends on the queries is a streaming pass after the tree-GRU
                     part_d = dv[ix["PART32"]] if self.share_swapped_pairs else None
                     pa["pooled_vab"] = (ops.pair_pool(vab, union_d, cfg.REL_SPATIAL_SCALE, ps, partner=part_d)
-                                        if self.side_stream and self.split_pair_pool is True else None)
+                                        if vab is not None and self.side_stream and self.split_pair_pool is True else None)
                 else:
                     vmap = self._gemm(fm2, "vmap", [self.spatio_atten_map]).view(B, fmap.shape[1], fmap.shape[2], low)
                 # semantic branch inputs that only need the detection heads (:1643-1668, :1066-1069): the subject /
@@ -1123,7 +1140,7 @@ class Generalized_RCNN(PackedLinears):
             r2c = self._gemm(reg_agg_relu, "r2c", [ct3.r2c[1]], out_f32=True)
             ev_r2c = None
             if (fork_b or os.environ.get("TRACE_TAIL_SPLIT")) and self.side_stream and self.fuse_pair_infer and \
-                    self.split_pair_pool == "tail":
+                    self.split_pair_pool == "tail" and vab is not None:
                 # the union-box pooling of the pair kernel depends on nothing computed after part A: it runs on the
                 # second stream beside the object temporal branch, the tree-GRU (32 workgroups) and the query GEMMs -
                 # a chain of small launches that leaves most CUs idle - and only the combine stays on the critical path
@@ -1168,7 +1185,11 @@ class Generalized_RCNN(PackedLinears):
             q_so = self._gemm(lo, "att_so", [self.spatio_atten_s[1], self.spatio_atten_o[1]])
             q_s, q_o = q_so[:, :low], q_so[:, low:]
             qk = ops.gemm_nt(q_so.view(2 * Ntot, low), kmap.view(-1, low), out_f32=True)   # (2*Ntot, B*h*w)
-            if pa.get("pooled_vab") is not None:
+            if pa.get("vabT") is not None:
+                sp = ops.pair_infer_mfma(pa["vabT"], (fmap.shape[1], fmap.shape[2]), pa["b_vab"], qk, union_d, dv[ix["X32"]],
+                                         dv[ix["Y32"]], bias_ab, cfg.REL_SPATIAL_SCALE, ps,
+                                         partner=dv[ix["PART32"]] if self.share_swapped_pairs else None, work=dv[ix["PWORK"]])
+            elif pa.get("pooled_vab") is not None:
                 if ev_r2c is not None:
                     main.wait_stream(side)
                 sp = ops.pair_combine(pa["pooled_vab"], tuple(vab.shape[:3]), qk, union_d, dv[ix["X32"]], dv[ix["Y32"]],

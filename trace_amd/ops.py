@@ -433,23 +433,27 @@ def tile_weights(w):
     return torch.gather(t, 3, src).contiguous().view(N, K)
 
 
-def gemm_nt_dual(A, A2, B, bias=None, relu=False):
+def gemm_nt_dual(A, A2, B, bias=None, relu=False, out_f32=False, out2=None):
     """relu?([A | A2] @ B^T + bias): A (M,K1), A2 (M,K2) bf16 row-strided views, B (N, K1+K2) bf16; K1, K2 % 64 == 0.
-    One launch for relu(conv3(h) + downsample(x)) of a bottleneck with a stride-1 downsample."""
+    One launch for relu(conv3(h) + downsample(x)) of a bottleneck with a stride-1 downsample.
+    out_f32 / out2 as in `gemm_nt` (f32 result plus its bf16 copy: the f32 residual stream of the late stages)."""
     _, M, lda, _ = _rows(A, "A")
     _, M2, lda2, _ = _rows(A2, "A2")
     _, N, ldb, _ = _rows(B, "B")
     K1, K2 = A.shape[-1], A2.shape[-1]
     if A.dim() != 2 or A2.dim() != 2 or B.dim() != 2 or M2 != M or B.shape[1] != K1 + K2:
         raise RuntimeError("gemm_nt_dual: shape mismatch")
-    out = torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else torch.bfloat16, device=A.device)
+    c2 = torch.empty((M, N), dtype=torch.bfloat16, device=A.device) if out2 is not None else None
     if bias is not None:
         bias = _f32(bias, "bias")
-    nbytes = 2 * (M * (K1 + K2) + N * (K1 + K2) + M * N)
+    epi = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    nbytes = 2 * (M * (K1 + K2) + N * (K1 + K2)) + out.numel() * out.element_size() + (2 * M * N if c2 is not None else 0)
     with torch.cuda.device(A.device), _span(2.0 * M * N * (K1 + K2), nbytes, "gemm_dual M=%d N=%d K=%d+%d" % (M, N, K1, K2)):
-        L.check(L.lib().trace_gemm_bf16_nt_dual(L.ptr(A), lda, K1, L.ptr(A2), lda2, K2, L.ptr(B), ldb, M, N, N, L.ptr(bias),
-                                                None, EPI_RELU if relu else 0, L.ptr(out), L.stream()), "gemm_bf16_nt_dual")
-    return out
+        L.check(L.lib().trace_gemm_bf16_nt_dual_ex(L.ptr(A), lda, K1, L.ptr(A2), lda2, K2, L.ptr(B), ldb, M, N, N, L.ptr(bias),
+                                                   None, epi, L.ptr(out), L.ptr(c2), _ACT[out2] if out2 is not None else 0,
+                                                   L.stream()), "gemm_bf16_nt_dual")
+    return out if out2 is None else (out, c2)
 
 
 def gemm_nt(A, B, bias=None, residual=None, relu=False, alpha=1.0, out_f32=False, leaky=False,
@@ -648,6 +652,74 @@ def pair_infer(vab, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, poole
                                                L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()),
                                                None if partner is None else L.ptr(partner), P, L.ptr(bias),
                                                float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_infer")
+    return sp
+
+
+PAIR_MFMA_PITCH = 224
+
+
+def pair_mfma_supported(H, W, pooled, D):
+    """Shapes trace_pair_infer_mfma takes: maps of at most 16 x 16 pixels (H*W + 31 <= the 224-pixel pitch), pooled <= 8."""
+    return H <= 16 and W <= 16 and pooled <= 8 and (H * W + 7) // 8 * 8 + 24 <= PAIR_MFMA_PITCH and D % 32 == 0 and D <= 512
+
+
+def pair_maps_channel_major(fmap, w_vab):
+    """fmap (B,H,W,C) bf16, w_vab (3D, C) bf16 -> vabT (B, 3D, 224) bf16 = w_vab fmap^T per clip (NO bias), pixel axis
+    contiguous and zero-padded: the operand layout of `pair_infer_mfma`."""
+    fmap = _bf16(fmap, "fmap")
+    B, H, W, C = fmap.shape
+    vabT = torch.zeros((B, w_vab.shape[0], PAIR_MFMA_PITCH), dtype=torch.bfloat16, device=fmap.device)
+    gemm_nt(w_vab, fmap.view(B, H * W, C), out=vabT[:, :, :H * W])
+    return vabT
+
+
+def pair_work_records(X, Y, union, partner):
+    """Host side (numpy): the work list of `pair_infer_mfma` - one 12-word record per union box to pool: [pair p, swapped
+    pair q or -1, X[p], Y[p], union[p] (5 floats, bit patterns), 0, 0, 0], for every pair that has no swapped partner
+    or is the lower index of one."""
+    import numpy as np
+    X, Y = np.asarray(X, np.int32).reshape(-1), np.asarray(Y, np.int32).reshape(-1)
+    part = np.asarray(partner, np.int32).reshape(-1) if partner is not None else np.full(X.shape[0], -1, np.int32)
+    lead = np.nonzero((part < 0) | (part > np.arange(X.shape[0])))[0]
+    rec = np.zeros((lead.shape[0], 12), np.int32)
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = lead, part[lead], X[lead], Y[lead]
+    rec[:, 4:9] = np.ascontiguousarray(np.asarray(union, np.float32)[lead]).view(np.int32)
+    return rec
+
+
+def pair_infer_mfma(vabT, map_hw, vbias, qk, rel_rois, sbj_inds, obj_inds, bias, spatial_scale, pooled=7, partner=None,
+                    work=None):
+    """`pair_infer` on the matrix cores: vabT (B,3D,224) bf16 from `pair_maps_channel_major`, map_hw = (H, W), vbias (3D)
+    f32 = the bias of the map GEMM (or None).  Same result as pair_infer up to bf16 rounding of the pooling weights.
+    work: (n, 12) int32 device tensor of `pair_work_records` (then rel_rois / indices / partner are only used for P)."""
+    vabT = _bf16(vabT, "vabT")
+    rel_rois, bias = _f32(rel_rois), _f32(bias)
+    L.require_gpu(sbj_inds, obj_inds, qk)
+    if qk.dtype != torch.float32 or qk.dim() != 2 or qk.stride(1) != 1:
+        raise RuntimeError("pair_infer_mfma: qk must be 2-D f32 with contiguous rows")
+    if sbj_inds.dtype != torch.int32 or obj_inds.dtype != torch.int32:
+        raise RuntimeError("pair_infer_mfma: indices must be int32")
+    B, D3, ldp = vabT.shape
+    D = D3 // 3
+    H, W = map_hw
+    P = rel_rois.shape[0]
+    if qk.shape[1] < B * H * W or bias.numel() != D or ldp != PAIR_MFMA_PITCH:
+        raise RuntimeError("pair_infer_mfma: qk / bias / pitch mismatch")
+    if vbias is not None:
+        vbias = _f32(vbias)
+        if vbias.numel() != D3:
+            raise RuntimeError("pair_infer_mfma: vbias must hold 3D values")
+    if work is not None:
+        L.require_gpu(work)
+        if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 12 or not work.is_contiguous():
+            raise RuntimeError("pair_infer_mfma: work must be a contiguous (n, 12) int32 tensor (ops.pair_work_records)")
+    sp = torch.empty((P, pooled * pooled, D), dtype=torch.bfloat16, device=vabT.device)
+    with torch.cuda.device(vabT.device):
+        L.check(L.lib().trace_pair_infer_mfma(L.ptr(vabT), B, H, W, D, ldp, L.ptr(vbias), L.ptr(qk), qk.stride(0),
+                                              L.ptr(rel_rois), L.ptr(sbj_inds.contiguous()), L.ptr(obj_inds.contiguous()),
+                                              _partner_ptr(partner, P, "pair_infer_mfma"), P,
+                                              None if work is None else L.ptr(work), 0 if work is None else int(work.shape[0]),
+                                              L.ptr(bias), float(spatial_scale), pooled, L.ptr(sp), L.stream()), "pair_infer_mfma")
     return sp
 
 

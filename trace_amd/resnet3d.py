@@ -161,6 +161,12 @@ class NonLocal3d(nn.Module):
                 S = ops.gemm_nt(phiT, gT)                                    # (N, c, c): S[i][j] = sum_kv phi[kv][i] g[kv][j]
                 w_out, b_out = self.conv_out.packed()
                 Mb = ops.gemm_nt(w_out, S, alpha=1.0 / nkv)                  # (N, C, c) = W_out S^T / N_kv
+                x32 = getattr(x, "_res32", None)
+                if x32 is not None:      # f32 residual stream (Bottleneck3d.res_f32): f32 sum + its bf16 rounding
+                    o32, o16 = ops.gemm_nt(theta, Mb, bias=b_out, residual=x32.view(N, nq, C), out_f32=True, out2="none")
+                    out = o16.view(N, T, H, W, C)
+                    out._res32 = o32.view(N, T, H, W, C)
+                    return out
                 out = ops.gemm_nt(theta, Mb, bias=b_out, residual=x.view(N, nq, C))
                 return out.view(N, T, H, W, C)
             phi, gT, nkv = ops.nl_pool_split(tpg, c)
@@ -225,11 +231,18 @@ class Bottleneck3d(nn.Module):
         out = torch.relu(self.conv3(self.conv2(self.conv1(x))) + identity)
         return self.non_local_block(out) if self.non_local else out
 
+    res_f32 = False   # set per block by ResNet3d (res_f32_stages): the block's output also exists in f32 (`out._res32`)
+
     def run(self, x, pool_t2=False):
-        """pool_t2: the MaxPool3d((2,1,1)) that follows this block (pool2 after layer1) rides in conv3's epilogue."""
+        """pool_t2: the MaxPool3d((2,1,1)) that follows this block (pool2 after layer1) rides in conv3's epilogue.
+        With `res_f32` the residual stream stays in f32: conv3's epilogue adds the f32 identity, writes the f32 sum and -
+        second output of the same launch - its bf16 rounding, which is what the next convs read as their operand; the
+        f32 twin travels as `out._res32`.  Only conv OPERANDS are rounded to bf16 then, never the running sum."""
         ds = self.downsample
-        if (self.fuse_downsample and ds is not None and tuple(ds.conv.stride) == (1, 1, 1) and tuple(ds.conv.kernel_size) == (1, 1, 1)
-                and x.shape[-1] % 64 == 0 and self.conv3.conv.in_channels % 64 == 0 and not pool_t2):
+        f32 = self.res_f32 and not pool_t2
+        fusable = (self.fuse_downsample and ds is not None and tuple(ds.conv.stride) == (1, 1, 1) and tuple(ds.conv.kernel_size) == (1, 1, 1)
+                   and x.shape[-1] % 64 == 0 and self.conv3.conv.in_channels % 64 == 0 and not pool_t2)
+        if fusable:
             # relu(conv3(h) + downsample(x)) as ONE GEMM over [h | x] with weights [W3 | Wd]: the downsample output is
             # neither written nor re-read as the residual (layer1's and, with DC5, layer4's first block)
             h = self.conv2.run(self.conv1.run(x))
@@ -237,8 +250,24 @@ class Bottleneck3d(nn.Module):
                 (w3, b3), (wd, bd) = self.conv3.packed(), ds.packed()
                 self._wcat = (torch.cat([w3, wd], 1).contiguous(), (b3 + bd).contiguous(), _PACK_EPOCH[0])
             N_, T_, H_, W_, _ = h.shape
-            out = ops.gemm_nt_dual(h.view(-1, h.shape[-1]), x.view(-1, x.shape[-1]), self._wcat[0], bias=self._wcat[1],
-                                   relu=True).view(N_, T_, H_, W_, -1)
+            res = ops.gemm_nt_dual(h.view(-1, h.shape[-1]), x.view(-1, x.shape[-1]), self._wcat[0], bias=self._wcat[1],
+                                   relu=True, out_f32=f32, out2="none" if f32 else None)
+            out = self._twin(res, (N_, T_, H_, W_, -1))
+            return self.non_local_block.run(out) if self.non_local else out
+        if f32:
+            x32 = getattr(x, "_res32", None)
+            if ds is not None:
+                c = ds.conv
+                w, b = ds.packed()
+                identity = ops.conv3d(x, w, b, c.kernel_size, c.stride, c.padding, c.dilation, out_f32=True)
+            else:
+                identity = x32 if x32 is not None else x.float()
+            h = self.conv2.run(self.conv1.run(x))
+            w3, b3 = self.conv3.packed()
+            N_, T_, H_, W_, _ = h.shape
+            res = ops.gemm_nt(h.view(-1, h.shape[-1]), w3, bias=b3, residual=identity.reshape(-1, w3.shape[0]), relu=True,
+                              out_f32=True, out2="none")                                                # resnet3d.py:306,313
+            out = self._twin(res, (N_, T_, H_, W_, -1))
             return self.non_local_block.run(out) if self.non_local else out
         identity = x if ds is None else ds.run(x)
         out = self.conv2.run(self.conv1.run(x))
@@ -249,6 +278,15 @@ class Bottleneck3d(nn.Module):
             if pool_t2:
                 out = ops.maxpool3d(out, (2, 1, 1), (2, 1, 1))
         return out
+
+    @staticmethod
+    def _twin(res, shape):
+        """(f32, bf16) pair of one launch -> the bf16 tensor carrying its f32 twin; a plain tensor passes through."""
+        if isinstance(res, tuple):
+            out = res[1].view(*shape)
+            out._res32 = res[0].view(*shape)
+            return out
+        return res.view(*shape)
 
 
 class ResNet3d(nn.Module):
@@ -332,6 +370,11 @@ class ResNet3d(nn.Module):
 
     # -- stem ---------------------------------------------------------------
     CP = 4  # clip channels padded 3 -> 4 (8-byte pixels)
+    # residual stages (0-based) whose residual stream stays in f32 (Bottleneck3d.res_f32), e.g. (2, 3).  OFF by default:
+    # measured in round 3 (tests/test_e2e_gpu.py, 2 x 32 frames, regime B) the free-running drift of layer4 against the
+    # fp32 reference moves from 2.30e-2 to 2.23e-2 only - the drift comes from rounding the conv OPERANDS (the floor with
+    # exact accumulation and f32 activations is 1.6e-2), not from re-rounding the running sum - at 0.4 % of the step
+    res_f32_stages = ()
     pixel_means = None     # per-channel means subtracted from uint8 frames (cfg.PIXEL_MEANS); None: 0
     stem_from_f32 = True   # TRACE's stem shape reads the f32 clip directly (ops.conv3d_stem_f32); False: padded bf16 copy first
 
@@ -414,6 +457,7 @@ class ResNet3d(nn.Module):
                 blocks = list(getattr(self, name))
                 for bi, blk in enumerate(blocks):
                     # pool2 (resnet3d.py:798-799) rides in the epilogue of layer1's last conv3
+                    blk.res_f32 = i in self.res_f32_stages
                     x = blk.run(x, pool_t2=(i == 0 and self.with_pool2 and bi == len(blocks) - 1))
                     if ops.PROBE is not None:
                         ops.PROBE.append(("%s.%d" % (name, bi), x))
