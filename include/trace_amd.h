@@ -439,6 +439,20 @@ int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups,
                    float* h, float* hd,
                    float* workspace /* n_nodes*n_groups*Hd f32 */,
                    trace_stream_t stream);
+/* The same pass with the workspace size stated.  With trace_tree_gru_workspace_bytes(...) bytes (8 planes of
+ * n_nodes*n_groups*Hd f32 when the wide kernels apply, else 1) matrices that do not fit LDS (Action Genome:
+ * F = Hd = 256, model_builder_rel.py:1009-1016 with cluster_tree3d.py:70-75) run as batched products streamed from
+ * L2 (tree_xterms_kernel + tree_gru_wide_kernel) instead of per-lane dot products; a smaller workspace (at least
+ * one plane, else an error) selects the kernels of trace_tree_gru. */
+size_t trace_tree_gru_workspace_bytes(int n_nodes, int F, int Hd, int n_groups);
+int trace_tree_gru_ex(const float* x, int n_nodes, int F, int Hd, int n_groups,
+                      int n_trees, const int32_t* tree_off,
+                      const int32_t* level_off, const int32_t* n_levels,
+                      const int32_t* parent, const int32_t* child_off,
+                      const int32_t* child_idx,
+                      const trace_tree_gru_weights* weights /* host, n_groups */,
+                      int max_tree_nodes, float* h, float* hd,
+                      float* workspace, size_t workspace_bytes, trace_stream_t stream);
 
 /* Glue of the relation head (csrc/glue_ops.hip): each replaces a chain of small torch ops of the reference
  * by one launch.  `act` = 0 | TRACE_EPI_RELU | TRACE_EPI_LEAKY.

@@ -21,11 +21,14 @@ def test_temporal_attention():
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("lds_resident", [False, True])
-@pytest.mark.parametrize("n,G,F_,Hd", [(1, 1, 64, 64), (7, 4, 64, 64), (20, 4, 64, 64), (33, 2, 256, 256)])
+@pytest.mark.parametrize("lds_resident", [False, True, "narrow"])
+@pytest.mark.parametrize("n,G,F_,Hd", [(1, 1, 64, 64), (7, 4, 64, 64), (20, 4, 64, 64), (33, 2, 256, 256), (50, 4, 256, 256),
+                                       (19, 1, 128, 512)])
 def test_tree_gru_vs_dense_reference(n, G, F_, Hd, lds_resident):
-    """tree-GRU on CSR arrays (HIP; the level-walking kernel and the LDS-resident one selected by a
-    tree-size bound) vs the reference's dense-adjacency formulation (oracle)."""
+    """tree-GRU on CSR arrays (HIP; the level-walking kernel, the LDS-resident one selected by a tree-size bound, and -
+    for matrices beyond LDS, 256 x 256 of the Action Genome head - the batched products streamed from L2; "narrow" =
+    the one-plane workspace, which keeps the level-walking kernel at every size) vs the reference's dense-adjacency
+    formulation (oracle)."""
     from trace_amd import ops, cluster_tree as ct
     from oracle import np_oracle
     from oracle.head_ref import _tree_gru
@@ -60,8 +63,8 @@ def test_tree_gru_vs_dense_reference(n, G, F_, Hd, lds_resident):
             d["br" + sfx] = sd["tm.%d.Ur%s.0.bias" % (gi, sfx)].to(DEV)
         w.append(d)
     x = torch.cat(feats, 0)
-    bound = max(t["parent"].shape[0] for t in trees) if lds_resident else 0
-    h, hd = ops.tree_gru(x.to(DEV), F_, Hd, G, forest, w, max_tree_nodes=bound)
+    bound = max(t["parent"].shape[0] for t in trees) if lds_resident is True else 0
+    h, hd = ops.tree_gru(x.to(DEV), F_, Hd, G, forest, w, max_tree_nodes=bound, wide=lds_resident != "narrow")
     off = 0
     for b, tree in enumerate(trees):
         nt = tree["parent"].shape[0]
@@ -75,6 +78,10 @@ def test_tree_gru_vs_dense_reference(n, G, F_, Hd, lds_resident):
             torch.testing.assert_close(h[off:off + nt, gi * Hd:(gi + 1) * Hd].cpu(), ref_h, rtol=2e-4, atol=2e-5)
         off += nt
     assert bool(torch.isfinite(h).all()) and bool(torch.isfinite(hd).all())
+    if lds_resident is False:   # every kernel choice computes the same pass (also where F != Hd has no oracle form)
+        h2, hd2 = ops.tree_gru(x.to(DEV), F_, Hd, G, forest, w, max_tree_nodes=0, wide=False)
+        torch.testing.assert_close(h, h2, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(hd, hd2, rtol=2e-4, atol=2e-5)
     # hd check through FFN2 = identity, FFN1 = 0
     if F_ == Hd:
         for gi in range(G):

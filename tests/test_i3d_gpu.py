@@ -57,8 +57,10 @@ def test_i3d_forward_matches_oracle(T, HW):
     compounds through ~50 BatchNorm layers of a random-weight network: the oracle's own
     bf16-emulation mode (same fp32 algorithm, stored tensors rounded to bf16) sits 5.5e-2 (rel. L2)
     from the fp32 oracle at layer4, and so does the HIP path; two bf16 executions that differ only
-    in summation order sit 2.8e-2 apart (8.4e-2 / 17 frames).  The end-to-end bounds below are therefore 1.2e-1 (vs fp32)
-    and 5e-2 (vs the emulation); the north_star 2e-2 bar is held per stage by
+    in summation order sit 2.8e-2 apart (5.5e-2 / 17 frames).  Measured (round 3, printed below): T=8 0.031 vs the
+    emulation, 0.055 vs fp32, fused-vs-unfused 0.041; T=17 0.038 / 0.086 / 0.055.  The bounds are those figures plus a
+    fifth, and the HIP path may not sit further from fp32 than 1.25 x the emulation itself does (the reference's own
+    algorithm with bf16 storage); the north_star 2e-2 bar is held per stage by
     test_i3d_stages_teacher_forced_rtol_2e2 and per layer by tests/test_igemm_gpu.py."""
     from oracle.i3d_ref import i3d_forward
     m = make_model()
@@ -79,17 +81,18 @@ def test_i3d_forward_matches_oracle(T, HW):
     assert out.shape == ref.shape
     emax, el2 = rel_err(out, emu)
     print("i3d T=%d HW=%d: vs bf16-emulating oracle %.4f" % (T, HW, el2))
-    assert el2 < 5e-2, ("vs bf16-emulating oracle", emax, el2)
+    assert el2 < 4.5e-2, ("vs bf16-emulating oracle", emax, el2)
+    _, emu_ref = rel_err(emu, ref)
     emax, el2 = rel_err(out, ref)
-    print("i3d T=%d HW=%d: vs fp32 oracle %.4f" % (T, HW, el2))
-    assert el2 < 1.2e-1, ("vs fp32 oracle", emax, el2)
+    print("i3d T=%d HW=%d: vs fp32 oracle %.4f (the bf16 emulation itself: %.4f)" % (T, HW, el2, emu_ref))
+    assert el2 < 1.0e-1 and el2 < 1.25 * emu_ref, ("vs fp32 oracle", emax, el2, emu_ref)
     fused = m(clip.to(DEV)).cpu()
     emax, el2 = rel_err(fused, ref)
     print("i3d T=%d HW=%d: fused downsample vs fp32 oracle %.4f" % (T, HW, el2))
-    assert el2 < 1.2e-1, ("fused downsample vs fp32 oracle", emax, el2)
+    assert el2 < 1.0e-1 and el2 < 1.25 * emu_ref, ("fused downsample vs fp32 oracle", emax, el2, emu_ref)
     emax, el2 = rel_err(fused, out)
     print("i3d T=%d HW=%d: fused vs unfused %.4f" % (T, HW, el2))
-    assert el2 < 8.4e-2, ("fused vs unfused downsample", emax, el2)
+    assert el2 < 6.5e-2, ("fused vs unfused downsample", emax, el2)
 
 
 def test_i3d_stages_teacher_forced_rtol_2e2():

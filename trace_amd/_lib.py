@@ -78,6 +78,9 @@ SIGNATURES = {
     "trace_pair_combine": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, P, P, P, c_int, P, c_float, c_int, P, P]),
     "trace_tree_gru": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
                                ctypes.POINTER(TreeGruWeights), c_int, P, P, P, P]),
+    "trace_tree_gru_ex": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P,
+                                  ctypes.POINTER(TreeGruWeights), c_int, P, P, P, c_size_t, P]),
+    "trace_tree_gru_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
 }
 
 _lib = None

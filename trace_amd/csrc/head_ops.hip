@@ -1196,6 +1196,245 @@ __global__ __launch_bounds__(512) void tree_gru_lds_kernel(const TreeParams p, i
 
 
 // ---------------------------------------------------------------------------
+// Tree-GRU, wide variant (Action Genome head: F = Hd = 256; any Hd in {64,128,256,512,1024}).  One direction's
+// matrices (6 x 256 KB) fit neither LDS nor the per-lane dot products of tree_gru_kernel (one L2 round trip per 4
+// MACs on a ~40-phase dependent chain: 11 ms at 50 objects per clip).  Here every matrix-vector product of the pass is
+// batched over up to TW_NV nodes and the matrix is streamed from L2 exactly once per batch:
+//   * tree_xterms_kernel: the input terms W{z,r,h}{,d} x_v of ALL nodes, groups and both directions - no dependence
+//     between nodes, one workgroup per (8 nodes, group, matrix), the whole chip;
+//   * tree_gru_wide_kernel: one workgroup of 1024 threads per (tree, group) walks the levels.  A product U v is
+//     computed for the level's nodes 8 at a time: the vectors sit in LDS (broadcast reads), thread (column j, K-slice
+//     s) reads its rows of column j once (coalesced) and keeps 8 partial sums, the K-slices are added in fixed order
+//     through LDS.  U_r h_c is computed when h_c is final (once per node instead of once per edge), U_z is applied
+//     to the sum of the children states (linear), and the top-down gates take U_{r,z}d hd_f per PARENT.
+// Workspace: 6 input-term planes + 2 product planes of n_nodes x G*Hd f32 (trace_tree_gru_workspace_bytes).
+// ---------------------------------------------------------------------------
+constexpr int TW_THREADS = 1024;
+constexpr int TW_NV = 8;
+
+// partial sums over this thread's K-slice rows [i0, i0 + rows) of column j; vs: LDS vectors (n, ldv)
+__device__ __forceinline__ void tw_partial(const float* __restrict__ Mt, int Hd, int j, int i0, int rows,
+                                           const float* vs, int ldv, int kk, float (&acc)[TW_NV]) {
+#pragma unroll
+  for (int n = 0; n < TW_NV; ++n) acc[n] = 0.f;
+  const float* mp = Mt + (long long)i0 * Hd + j;
+#pragma unroll 2
+  for (int i = 0; i < rows; i += 4) {
+    const float m0 = mp[0], m1 = mp[Hd], m2 = mp[2 * Hd], m3 = mp[3 * Hd];
+    mp += 4 * Hd;
+#pragma unroll
+    for (int n = 0; n < TW_NV; ++n) {
+      if (n < kk) {
+        const float4 x = *reinterpret_cast<const float4*>(vs + n * ldv + i0 + i);
+        acc[n] += m0 * x.x;
+        acc[n] += m1 * x.y;
+        acc[n] += m2 * x.z;
+        acc[n] += m3 * x.w;
+      }
+    }
+  }
+}
+
+struct TreeWideParams {
+  TreeParams t;
+  float* xt;        // 6 planes (z, r, h up; z, r, h down) of n_nodes x G*Hd
+  float* pa;        // product plane A: U_r h_c (bottom-up), U_rd hd_f (top-down)
+  float* pb;        // product plane B: U_zd hd_f
+  int n_nodes;
+};
+
+__global__ __launch_bounds__(TW_THREADS) void tree_xterms_kernel(const TreeWideParams q) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const TreeParams& p = q.t;
+  const int F = p.F, Hd = p.Hd;
+  const int g = blockIdx.y, m = blockIdx.z;
+  const int v0 = blockIdx.x * TW_NV;
+  const int kk = min(TW_NV, q.n_nodes - v0);
+  const TreeW& w = p.w[g];
+  const float* Wm = m == 0 ? w.Wz : m == 1 ? w.Wr : m == 2 ? w.Wh : m == 3 ? w.Wzd : m == 4 ? w.Wrd : w.Whd;
+  float* vs = sm;                       // [TW_NV][F]
+  float* part = sm + TW_NV * F;         // [slices][TW_NV][Hd]
+  const long long ldx = (long long)p.G * F, ldh = (long long)p.G * Hd;
+  for (int e = threadIdx.x * 4; e < kk * F; e += TW_THREADS * 4) {
+    const int n = e / F, i = e - n * F;
+    *reinterpret_cast<float4*>(vs + n * F + i) = *reinterpret_cast<const float4*>(p.x + (v0 + n) * ldx + (long long)g * F + i);
+  }
+  __syncthreads();
+  const int n_slices = TW_THREADS / Hd;
+  const int j = threadIdx.x % Hd, sl = threadIdx.x / Hd;
+  const int rows = F / n_slices;
+  float acc[TW_NV];
+  tw_partial(Wm, Hd, j, sl * rows, rows, vs, F, kk, acc);
+#pragma unroll
+  for (int n = 0; n < TW_NV; ++n) part[(sl * TW_NV + n) * Hd + j] = acc[n];
+  __syncthreads();
+  float* out = q.xt + (long long)m * q.n_nodes * ldh + (long long)g * Hd;
+  for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+    const int n = e / Hd, c = e - n * Hd;
+    float s = 0.f;
+    for (int k = 0; k < n_slices; ++k) s += part[(k * TW_NV + n) * Hd + c];
+    out[(v0 + n) * ldh + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(TW_THREADS) void tree_gru_wide_kernel(const TreeWideParams q) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const TreeParams& p = q.t;
+  const int t = blockIdx.x, g = blockIdx.y;
+  const TreeW& w = p.w[g];
+  const int Hd = p.Hd;
+  const long long ldh = (long long)p.G * Hd;
+  const long long plane = (long long)q.n_nodes * ldh;
+  float* vsA = sm;                          // [TW_NV][Hd]
+  float* vsB = vsA + TW_NV * Hd;            // [TW_NV][Hd]
+  float* partA = vsB + TW_NV * Hd;          // [slices][TW_NV][Hd] = TW_NV * 1024
+  float* partB = partA + TW_NV * TW_THREADS;
+  __shared__ int lo[TRACE_TREE_MAX_LEVELS + 2];
+  const int nl = p.n_levels[t];
+  for (int i = threadIdx.x; i <= TRACE_TREE_MAX_LEVELS; i += TW_THREADS)
+    lo[i] = p.level_off[(long long)t * (TRACE_TREE_MAX_LEVELS + 1) + i];
+  float* h = p.h + (long long)g * Hd;
+  float* hd = p.hd + (long long)g * Hd;
+  float* pa = q.pa + (long long)g * Hd;
+  float* pb = q.pb + (long long)g * Hd;
+  const float* xz = q.xt + (long long)g * Hd;
+  const float* xr = xz + plane;
+  const float* xh = xr + plane;
+  const int n_slices = TW_THREADS / Hd;
+  const int j = threadIdx.x % Hd, sl = threadIdx.x / Hd;
+  const int rows = Hd / n_slices, i0 = sl * rows;
+  float acc[TW_NV];
+  auto put = [&](float* part) {
+#pragma unroll
+    for (int n = 0; n < TW_NV; ++n) part[(sl * TW_NV + n) * Hd + j] = acc[n];
+  };
+  auto total = [&](const float* part, int n, int c) {
+    float s = 0.f;
+    for (int k = 0; k < n_slices; ++k) s += part[(k * TW_NV + n) * Hd + c];
+    return s;
+  };
+  __syncthreads();
+
+  // ================= bottom-up (cluster_tree.py:281-316)
+  for (int l = 0; l < nl; ++l) {
+    for (int v0 = lo[l]; v0 < lo[l + 1]; v0 += TW_NV) {
+      const int kk = min(TW_NV, lo[l + 1] - v0);
+      if (l == 0) {
+        // leaves (:289-292): no bias on the leaf gates, as the reference
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          const long long o = (v0 + n) * ldh + c;
+          const float z = sigmoidf_(xz[o]);
+          const float hv = (1.0f - z) * tanhf(xh[o]);
+          h[o] = hv;
+          vsB[n * Hd + c] = hv;
+        }
+        __syncthreads();
+      } else {
+        // gated and plain sums over the children (:296-306); U_r h_c was stored when h_c became final
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          const int v = v0 + n;
+          const float a = xr[v * ldh + c] + w.br[c];
+          float fa = 0.f, hs = 0.f;
+          for (int ci = p.child_off[v]; ci < p.child_off[v + 1]; ++ci) {
+            const long long oc = (long long)p.child_idx[ci] * ldh + c;
+            const float hc = h[oc];
+            fa += sigmoidf_(a + pa[oc]) * hc;
+            hs += hc;
+          }
+          vsA[n * Hd + c] = hs;
+          vsB[n * Hd + c] = fa;
+        }
+        __syncthreads();
+        tw_partial(w.Uz, Hd, j, i0, rows, vsA, Hd, kk, acc);
+        put(partA);
+        tw_partial(w.Uh, Hd, j, i0, rows, vsB, Hd, kk, acc);
+        put(partB);
+        __syncthreads();
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          const long long o = (v0 + n) * ldh + c;
+          const float z = sigmoidf_(xz[o] + w.bz[c] + total(partA, n, c));
+          const float cand = tanhf(xh[o] + total(partB, n, c));
+          const float hv = z * vsA[n * Hd + c] + (1.0f - z) * cand;
+          h[o] = hv;
+          vsB[n * Hd + c] = hv;
+        }
+        __syncthreads();
+      }
+      if (l < nl - 1) {   // the parent's reset gate needs U_r h_v
+        tw_partial(w.Ur, Hd, j, i0, rows, vsB, Hd, kk, acc);
+        put(partA);
+        __syncthreads();
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          pa[(v0 + n) * ldh + c] = total(partA, n, c);
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ================= top-down (cluster_tree.py:189-200, 318-352)
+  const float* xzd = xh + plane;
+  const float* xrd = xzd + plane;
+  const float* xhd = xrd + plane;
+  for (int l = nl - 1; l >= 0; --l) {
+    for (int v0 = lo[l]; v0 < lo[l + 1]; v0 += TW_NV) {
+      const int kk = min(TW_NV, lo[l + 1] - v0);
+      if (l == nl - 1) {
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {   // roots copy h
+          const int n = e / Hd, c = e - n * Hd;
+          const long long o = (v0 + n) * ldh + c;
+          const float hv = h[o];
+          hd[o] = hv;
+          vsA[n * Hd + c] = hv;
+        }
+        __syncthreads();
+      } else {
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          const int v = v0 + n;
+          const long long of = (long long)p.parent[v] * ldh + c;
+          const float r = sigmoidf_(xrd[v * ldh + c] + pa[of] + w.brd[c]);
+          vsB[n * Hd + c] = r * hd[of];
+        }
+        __syncthreads();
+        tw_partial(w.Uhd, Hd, j, i0, rows, vsB, Hd, kk, acc);
+        put(partA);
+        __syncthreads();
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          const int v = v0 + n;
+          const long long o = v * ldh + c, of = (long long)p.parent[v] * ldh + c;
+          const float z = sigmoidf_(xzd[o] + pb[of] + w.bzd[c]);
+          const float cand = tanhf(xhd[o] + total(partA, n, c));
+          const float hv = z * hd[of] + (1.0f - z) * cand;
+          hd[o] = hv;
+          vsA[n * Hd + c] = hv;
+        }
+        __syncthreads();
+      }
+      if (l > 0) {   // the children's gates need U_rd hd_v and U_zd hd_v
+        tw_partial(w.Urd, Hd, j, i0, rows, vsA, Hd, kk, acc);
+        put(partA);
+        tw_partial(w.Uzd, Hd, j, i0, rows, vsA, Hd, kk, acc);
+        put(partB);
+        __syncthreads();
+        for (int e = threadIdx.x; e < kk * Hd; e += TW_THREADS) {
+          const int n = e / Hd, c = e - n * Hd;
+          pa[(v0 + n) * ldh + c] = total(partA, n, c);
+          pb[(v0 + n) * ldh + c] = total(partB, n, c);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------
 // Triplet ranking: lib/datasets_rel/task_evaluation_vg_and_vrd.py:207-228 on device.
 //   per pair: the prd_k best predicates (:207-208), score = sbj * obj * prd (:214-215)
 //   per clip: the topk best (pair, predicate) cells (:227 argsort_desc()[:topk])
@@ -1518,12 +1757,24 @@ extern "C" int trace_pair_combine(const uint16_t* pooled_maps, int B, int H, int
   return check_launch("pair_combine");
 }
 
-extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,
-                              const int32_t* tree_off, const int32_t* level_off,
-                              const int32_t* n_levels, const int32_t* parent,
-                              const int32_t* child_off, const int32_t* child_idx,
-                              const trace_tree_gru_weights* weights, int max_tree_nodes, float* h,
-                              float* hd, float* workspace, trace_stream_t stream) {
+static bool tree_wide_ok(int F, int Hd) {
+  if (Hd < 64 || Hd > TW_THREADS || TW_THREADS % Hd != 0) return false;
+  const int n_slices = TW_THREADS / Hd;
+  return F % (4 * n_slices) == 0 && Hd % (4 * n_slices) == 0 && F <= 1024;
+}
+
+extern "C" size_t trace_tree_gru_workspace_bytes(int n_nodes, int F, int Hd, int n_groups) {
+  if (n_nodes < 0 || F <= 0 || Hd <= 0 || n_groups <= 0) return 0;
+  const size_t plane = (size_t)n_nodes * n_groups * Hd * sizeof(float);
+  return (tree_wide_ok(F, Hd) ? 8 : 1) * plane + 256;
+}
+
+static int tree_gru_impl(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,
+                         const int32_t* tree_off, const int32_t* level_off,
+                         const int32_t* n_levels, const int32_t* parent,
+                         const int32_t* child_off, const int32_t* child_idx,
+                         const trace_tree_gru_weights* weights, int max_tree_nodes, float* h,
+                         float* hd, float* workspace, size_t workspace_bytes, trace_stream_t stream) {
   TRACE_REQUIRE(n_nodes >= 0 && F > 0 && Hd > 0 && n_groups > 0 && n_trees >= 0, "tree_gru: bad shape");
   TRACE_REQUIRE(n_groups <= TRACE_TREE_MAX_GROUPS, "tree_gru: more than %d groups", TRACE_TREE_MAX_GROUPS);
   if (n_trees == 0 || n_nodes == 0) return 0;
@@ -1581,6 +1832,25 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
     }
   }
   const size_t lds = (size_t)(3 * F * Hd + 3 * Hd * Hd) * sizeof(float);
+  const size_t plane = (size_t)n_nodes * n_groups * Hd;
+  static const bool no_wide = getenv("TRACE_TREE_NO_WIDE") != nullptr;
+  if (lds > 128 * 1024 && !no_wide && tree_wide_ok(F, Hd) && workspace_bytes >= 8 * plane * sizeof(float)) {
+    // matrices too large for LDS: batched products streamed from L2 (see tree_gru_wide_kernel)
+    TreeWideParams q;
+    q.t = p;
+    q.xt = workspace;
+    q.pa = workspace + 6 * plane;
+    q.pb = workspace + 7 * plane;
+    q.n_nodes = n_nodes;
+    const size_t lds_x = (size_t)(TW_NV * F + TW_NV * TW_THREADS) * sizeof(float);
+    const size_t lds_w = (size_t)(2 * TW_NV * Hd + 2 * TW_NV * TW_THREADS) * sizeof(float);
+    TRACE_LDS_OPT_IN(&tree_xterms_kernel, 160 * 1024 - 256, "tree_gru");
+    TRACE_LDS_OPT_IN(&tree_gru_wide_kernel, 160 * 1024 - 256, "tree_gru");
+    hipLaunchKernelGGL(tree_xterms_kernel, dim3((n_nodes + TW_NV - 1) / TW_NV, n_groups, 6), dim3(TW_THREADS), lds_x,
+                       (hipStream_t)stream, q);
+    hipLaunchKernelGGL(tree_gru_wide_kernel, dim3(n_trees, n_groups), dim3(TW_THREADS), lds_w, (hipStream_t)stream, q);
+    return check_launch("tree_gru");
+  }
   if (lds <= 128 * 1024) {
     TRACE_LDS_OPT_IN(&tree_gru_kernel<true>, 128 * 1024, "tree_gru");
     hipLaunchKernelGGL(tree_gru_kernel<true>, dim3(n_trees, n_groups), dim3(256), lds, (hipStream_t)stream, p);
@@ -1588,6 +1858,30 @@ extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_
     hipLaunchKernelGGL(tree_gru_kernel<false>, dim3(n_trees, n_groups), dim3(256), 0, (hipStream_t)stream, p);
   }
   return check_launch("tree_gru");
+}
+
+extern "C" int trace_tree_gru(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,
+                              const int32_t* tree_off, const int32_t* level_off,
+                              const int32_t* n_levels, const int32_t* parent,
+                              const int32_t* child_off, const int32_t* child_idx,
+                              const trace_tree_gru_weights* weights, int max_tree_nodes, float* h,
+                              float* hd, float* workspace, trace_stream_t stream) {
+  return tree_gru_impl(x, n_nodes, F, Hd, n_groups, n_trees, tree_off, level_off, n_levels, parent, child_off, child_idx,
+                       weights, max_tree_nodes, h, hd, workspace, (size_t)(n_nodes > 0 ? n_nodes : 0) * n_groups * Hd * sizeof(float),
+                       stream);
+}
+
+extern "C" int trace_tree_gru_ex(const float* x, int n_nodes, int F, int Hd, int n_groups, int n_trees,
+                                 const int32_t* tree_off, const int32_t* level_off,
+                                 const int32_t* n_levels, const int32_t* parent,
+                                 const int32_t* child_off, const int32_t* child_idx,
+                                 const trace_tree_gru_weights* weights, int max_tree_nodes, float* h,
+                                 float* hd, float* workspace, size_t workspace_bytes, trace_stream_t stream) {
+  TRACE_REQUIRE(n_nodes >= 0 && n_groups > 0 && Hd > 0, "tree_gru: bad shape");
+  TRACE_REQUIRE(workspace_bytes >= (size_t)n_nodes * n_groups * Hd * sizeof(float),
+                "tree_gru: workspace of %zu bytes is smaller than n_nodes*n_groups*Hd f32", workspace_bytes);
+  return tree_gru_impl(x, n_nodes, F, Hd, n_groups, n_trees, tree_off, level_off, n_levels, parent, child_off, child_idx,
+                       weights, max_tree_nodes, h, hd, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t trace_rank_triplets_workspace_bytes(int P_total, int prd_k) {

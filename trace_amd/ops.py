@@ -770,17 +770,19 @@ def pair_combine(pooled_maps, map_shape, qk, rel_rois, sbj_inds, obj_inds, bias,
     return sp
 
 
-def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
+def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0, wide=True):
     """x (n_nodes, n_groups*F) f32; forest = dict(tree_off, level_off, n_levels, parent, child_off,
     child_idx) of int32 device tensors; weights = list (per group) of dicts holding the 16 TRANSPOSED
     f32 device tensors named as in trace_tree_gru_weights.  max_tree_nodes: host-known upper bound of the
-    nodes of one tree (enables the LDS-resident kernel).  Returns h, hd (n_nodes, n_groups*Hd)."""
+    nodes of one tree (enables the LDS-resident kernel).  wide=False: the one-plane workspace of trace_tree_gru
+    (never the batched-product kernels for matrices beyond LDS).  Returns h, hd (n_nodes, n_groups*Hd)."""
     x = _f32(x)
     n_nodes = x.shape[0]
     dev = x.device
     h = torch.empty((n_nodes, n_groups * Hd), dtype=torch.float32, device=dev)
     hd = torch.empty_like(h)
-    ws = torch.empty_like(h)
+    ws_bytes = int(L.lib().trace_tree_gru_workspace_bytes(n_nodes, F, Hd, n_groups)) if wide else h.numel() * 4
+    ws = torch.empty((max(ws_bytes, 4) + 3) // 4, dtype=torch.float32, device=dev)
     arr = (L.TreeGruWeights * n_groups)()
     keep = []
     for g in range(n_groups):
@@ -790,11 +792,11 @@ def tree_gru(x, F, Hd, n_groups, forest, weights, max_tree_nodes=0):
             setattr(arr[g], name, t.data_ptr())
     n_trees = forest["tree_off"].numel() - 1
     with torch.cuda.device(dev):
-        L.check(L.lib().trace_tree_gru(L.ptr(x), n_nodes, F, Hd, n_groups, n_trees, L.ptr(forest["tree_off"]),
-                                       L.ptr(forest["level_off"]), L.ptr(forest["n_levels"]),
-                                       L.ptr(forest["parent"]), L.ptr(forest["child_off"]),
-                                       L.ptr(forest["child_idx"]), arr, int(max_tree_nodes), L.ptr(h), L.ptr(hd), L.ptr(ws),
-                                       L.stream()), "tree_gru")
+        L.check(L.lib().trace_tree_gru_ex(L.ptr(x), n_nodes, F, Hd, n_groups, n_trees, L.ptr(forest["tree_off"]),
+                                          L.ptr(forest["level_off"]), L.ptr(forest["n_levels"]),
+                                          L.ptr(forest["parent"]), L.ptr(forest["child_off"]),
+                                          L.ptr(forest["child_idx"]), arr, int(max_tree_nodes), L.ptr(h), L.ptr(hd), L.ptr(ws),
+                                          ws.numel() * 4, L.stream()), "tree_gru")
     return h, hd
 
 
