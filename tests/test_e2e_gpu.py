@@ -164,8 +164,8 @@ def test_clip_to_triplets_vs_fp32_oracle(regime, B, T, n, with_labels):
             assert v < tol_head, (k, v, tol_head)
         assert prd_err < 2e-2, prd_err
         # layer4, free-running: never further from fp32 than the reference's own algorithm is once its stored tensors
-        # are bf16 (x 1.15 for summation order), and within 2.5e-2 in regime B (measured 2.2e-2 .. 2.35e-2)
-        assert e4 < 1.15 * emu4, ("layer4 vs fp32, free-running", e4, emu4, floor)
+        # are bf16 (x 1.06 for summation order; measured 0.96 .. 1.011), and within 2.5e-2 in regime B (measured 2.2e-2 .. 2.35e-2)
+        assert e4 < 1.06 * emu4, ("layer4 vs fp32, free-running", e4, emu4, floor)
         if regime == "B":
             assert e4 < 2.5e-2, ("layer4 vs fp32, free-running, regime B", e4, emu4, floor)
         misses = len(want) - len(want & got)

@@ -366,6 +366,33 @@ def test_rank_triplets_vs_oracle(prd_k, topk, big):
             assert np.array_equal(pair_ref, order // kk) and np.array_equal(prd_ref, lab.ravel()[order])
 
 
+@pytest.mark.parametrize("pairs", [[700, 60], [1200]])
+def test_rank_triplets_ties_at_the_cut(pairs):
+    """The selection path (more than 1024 candidates per clip): scores on a 4-value grid, zeros of both signs among
+    them, so that the topk-th score is shared by thousands of candidates - the cut has to fall in candidate-index
+    order, exactly as the stable sort puts it."""
+    from trace_amd import ops
+    rng = np.random.default_rng(len(pairs))
+    n_prd, prd_k, topk = 132, 20, 100
+    poff = np.concatenate([[0], np.cumsum(pairs)]).astype(np.int64)
+    P = int(poff[-1])
+    prd = rng.choice(np.array([0.0, 0.25, 0.5, 0.75], np.float32), size=(P, n_prd), p=[0.9, 0.06, 0.039, 0.001])
+    ss = rng.choice(np.array([1.0, -0.0, 1.0], np.float32), size=P)
+    os_ = np.ones(P, np.float32)
+    sl, ol = rng.integers(1, 36, P), rng.integers(1, 36, P)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    out = ops.rank_triplets(t(prd), t(ss), t(os_), t(sl), t(ol), t(poff), max(pairs), topk, prd_k)
+    for b, nb in enumerate(pairs):
+        sl_ = slice(int(poff[b]), int(poff[b + 1]))
+        lab = np.argsort(-prd[sl_], axis=1, kind="stable")[:, :prd_k]
+        sc = np.take_along_axis(prd[sl_], lab, 1)
+        spo = ((ss[sl_] * os_[sl_])[:, None] * sc).astype(np.float32)
+        order = np.argsort(-spo.ravel(), kind="stable")[:topk]
+        assert np.array_equal(out["top_scores"][b].cpu().numpy(), spo.ravel()[order])
+        assert np.array_equal(out["top_pair"][b].cpu().numpy(), order // prd_k)
+        assert np.array_equal(out["top_prd"][b].cpu().numpy(), lab.ravel()[order])
+
+
 def test_rank_triplets_rejects_oversize():
     """More segments x topk than the on-chip merge holds: a clear error, no silent fallback."""
     from trace_amd import ops

@@ -59,7 +59,7 @@ def test_i3d_forward_matches_oracle(T, HW):
     from the fp32 oracle at layer4, and so does the HIP path; two bf16 executions that differ only
     in summation order sit 2.8e-2 apart (5.5e-2 / 17 frames).  Measured (round 3, printed below): T=8 0.031 vs the
     emulation, 0.055 vs fp32, fused-vs-unfused 0.041; T=17 0.038 / 0.086 / 0.055.  The bounds are those figures plus a
-    fifth, and the HIP path may not sit further from fp32 than 1.25 x the emulation itself does (the reference's own
+    fifth, and the HIP path may not sit further from fp32 than 1.1 x the emulation itself does (measured 1.00 and 1.035) (the reference's own
     algorithm with bf16 storage); the north_star 2e-2 bar is held per stage by
     test_i3d_stages_teacher_forced_rtol_2e2 and per layer by tests/test_igemm_gpu.py."""
     from oracle.i3d_ref import i3d_forward
@@ -85,11 +85,11 @@ def test_i3d_forward_matches_oracle(T, HW):
     _, emu_ref = rel_err(emu, ref)
     emax, el2 = rel_err(out, ref)
     print("i3d T=%d HW=%d: vs fp32 oracle %.4f (the bf16 emulation itself: %.4f)" % (T, HW, el2, emu_ref))
-    assert el2 < 1.0e-1 and el2 < 1.25 * emu_ref, ("vs fp32 oracle", emax, el2, emu_ref)
+    assert el2 < 1.0e-1 and el2 < 1.1 * emu_ref, ("vs fp32 oracle", emax, el2, emu_ref)
     fused = m(clip.to(DEV)).cpu()
     emax, el2 = rel_err(fused, ref)
     print("i3d T=%d HW=%d: fused downsample vs fp32 oracle %.4f" % (T, HW, el2))
-    assert el2 < 1.0e-1 and el2 < 1.25 * emu_ref, ("fused downsample vs fp32 oracle", emax, el2, emu_ref)
+    assert el2 < 1.0e-1 and el2 < 1.1 * emu_ref, ("fused downsample vs fp32 oracle", emax, el2, emu_ref)
     emax, el2 = rel_err(fused, out)
     print("i3d T=%d HW=%d: fused vs unfused %.4f" % (T, HW, el2))
     assert el2 < 6.5e-2, ("fused vs unfused downsample", emax, el2)

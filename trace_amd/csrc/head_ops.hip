@@ -1491,6 +1491,136 @@ __global__ __launch_bounds__(256) void rank_pair_topk_kernel(const float* __rest
   }
 }
 
+__device__ __forceinline__ void rank_bitonic(float* key, int* idx, int npow2) {
+  for (int k = 2; k <= npow2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const float si = key[i], sj = key[ixj];
+          const int ii = idx[i], ij = idx[ixj];
+          const bool up = ((i & k) == 0);
+          const bool swap = up ? rank_before(sj, ij, si, ii) : rank_before(si, ii, sj, ij);
+          if (swap) {
+            key[i] = sj;
+            key[ixj] = si;
+            idx[i] = ij;
+            idx[ixj] = ii;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Top-k by selection instead of a full sort (prd_k = 20: 7 600 candidates per clip, 100 wanted - the full bitonic
+// sort of 8 192 slots was 198 us per step on 8 workgroups).  The k-th best score is found by a 4-pass radix select on
+// the order-preserving integer image of the scores (LDS histograms; integer atomics, so the result does not depend
+// on their order), the candidates above it plus the lowest-indexed ones equal to it are compacted (index order of
+// the ties by a prefix count over contiguous chunks) and only those k are sorted.  Same total order as the sort:
+// score descending, candidate index ascending.  blockDim.x == 1024, 1 <= k <= 1024, k < n; on return
+// key[0..k) / idx[0..k) hold the k best in rank order.
+__device__ __forceinline__ unsigned rank_ord(float f) {
+  const unsigned u = __float_as_uint(f + 0.0f);   // -0 -> +0: the two compare equal in rank_before
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ void rank_select_sort(float* key, int* idx, int n, int k, int idx_base) {
+  __shared__ int hist[256];
+  __shared__ int scan[1024];
+  __shared__ int res[2];
+  __shared__ float selk[1024];
+  __shared__ int seli[1024];
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned prefix = 0, mask = 0;
+  int need = k;   // how many of the candidates matching `prefix` are still wanted
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const unsigned u = rank_ord(key[i]);
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {   // lane: bins 255 - 4 lane .. 252 - 4 lane, i.e. descending digit
+      const int c0 = hist[255 - 4 * lane], c1 = hist[254 - 4 * lane], c2 = hist[253 - 4 * lane], c3 = hist[252 - 4 * lane];
+      const int sum = c0 + c1 + c2 + c3;
+      int inc = sum;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      const int exc = inc - sum;
+      if (exc < need && inc >= need) {
+        int run = exc, d = 255 - 4 * lane;
+        if (run + c0 < need) {
+          run += c0; --d;
+          if (run + c1 < need) {
+            run += c1; --d;
+            if (run + c2 < need) { run += c2; --d; }
+          }
+        }
+        res[0] = d;
+        res[1] = need - run;
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned)res[0] << shift;
+    mask |= 255u << shift;
+    need = res[1];
+  }
+  // prefix = the k-th best key; `need` of the candidates equal to it are taken, lowest index first
+  const int per = (n + 1023) >> 10;
+  const int i0 = min(n, tid * per), i1 = min(n, i0 + per);
+  int gt = 0, eq = 0;
+  for (int i = i0; i < i1; ++i) {
+    const unsigned u = rank_ord(key[i]);
+    gt += u > prefix;
+    eq += u == prefix;
+  }
+  const int own = (gt << 16) | eq;   // gt < k <= 1024, eq <= 16384
+  scan[tid] = own;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int t = tid >= off ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += t;
+    __syncthreads();
+  }
+  const int gt_total = scan[1023] >> 16;
+  int go = (scan[tid] - own) >> 16, eo = (scan[tid] - own) & 0xffff;
+  int np2 = 64;
+  while (np2 < k) np2 <<= 1;
+  for (int i = i0; i < i1; ++i) {
+    const float f = key[i] + 0.0f;
+    const unsigned u = rank_ord(f);
+    if (u > prefix) {
+      selk[go] = f;
+      seli[go] = idx_base + i;
+      ++go;
+    } else if (u == prefix) {
+      if (eo < need) {
+        selk[gt_total + eo] = f;
+        seli[gt_total + eo] = idx_base + i;
+      }
+      ++eo;
+    }
+  }
+  for (int i = k + tid; i < np2; i += 1024) {
+    selk[i] = -__builtin_inff();
+    seli[i] = 0x7fffffff;
+  }
+  __syncthreads();
+  rank_bitonic(selk, seli, np2);
+  for (int i = tid; i < k; i += 1024) {
+    key[i] = selk[i];
+    idx[i] = seli[i];
+  }
+  __syncthreads();
+}
+
 // One workgroup per clip: bitonic sort of the clip's P_b*kk candidates in LDS, first topk written out.
 __global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __restrict__ cand_score,
                                                               const int32_t* __restrict__ cand_prd,
@@ -1514,26 +1644,8 @@ __global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __res
     idx[i] = i < n ? i : 0x7fffffff;
   }
   __syncthreads();
-  for (int k = 2; k <= npow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float si = key[i], sj = key[ixj];
-          const int ii = idx[i], ij = idx[ixj];
-          const bool up = ((i & k) == 0);
-          const bool swap = up ? rank_before(sj, ij, si, ii) : rank_before(si, ii, sj, ij);
-          if (swap) {
-            key[i] = sj;
-            key[ixj] = si;
-            idx[i] = ij;
-            idx[ixj] = ii;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  if (n > 1024 && topk <= 1024 && blockDim.x == 1024) rank_select_sort(key, idx, n, topk, 0);   // uniform
+  else rank_bitonic(key, idx, npow2);
   for (int j = threadIdx.x; j < topk; j += blockDim.x) {
     const long long o = (long long)b * topk + j;
     if (j < n) {
@@ -1558,29 +1670,6 @@ __global__ __launch_bounds__(1024) void rank_clip_topk_kernel(const float* __res
 // (s, b) sorts segment s (RANK_MAX_CAND candidates) of clip b and keeps its topk best as (score, clip-local candidate
 // index); rank_merge_topk_kernel then sorts the n_seg x topk survivors of a clip.  Both sort on (score descending,
 // candidate index ascending) - the total order of the single-pass kernel - so the result is the same list, ties included.
-__device__ __forceinline__ void rank_bitonic(float* key, int* idx, int npow2) {
-  for (int k = 2; k <= npow2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const float si = key[i], sj = key[ixj];
-          const int ii = idx[i], ij = idx[ixj];
-          const bool up = ((i & k) == 0);
-          const bool swap = up ? rank_before(sj, ij, si, ii) : rank_before(si, ii, sj, ij);
-          if (swap) {
-            key[i] = sj;
-            key[ixj] = si;
-            idx[i] = ij;
-            idx[ixj] = ii;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 __global__ __launch_bounds__(1024) void rank_seg_topk_kernel(const float* __restrict__ cand_score,
                                                              const int64_t* __restrict__ poff, int kk, int topk,
                                                              int n_seg, float* __restrict__ seg_score,
@@ -1599,7 +1688,8 @@ __global__ __launch_bounds__(1024) void rank_seg_topk_kernel(const float* __rest
     idx[i] = i < cnt ? (int)(lo + i) : 0x7fffffff;
   }
   __syncthreads();
-  if (cnt > 0) rank_bitonic(key, idx, RANK_MAX_CAND);   // cnt is uniform over the workgroup
+  if (cnt > 1024 && topk <= 1024) rank_select_sort(key, idx, cnt, topk, (int)lo);   // cnt is uniform over the workgroup
+  else if (cnt > 0) rank_bitonic(key, idx, RANK_MAX_CAND);
   for (int j = threadIdx.x; j < topk; j += blockDim.x) {
     const long long o = ((long long)b * n_seg + sgm) * topk + j;
     seg_score[o] = j < cnt ? key[j] : -__builtin_inff();

@@ -80,6 +80,15 @@ constexpr int BK = 64;
 __device__ __forceinline__ int lds_off(int r, int chunk) {
   return r * 128 + ((chunk ^ (r & 7)) << 4);
 }
+// Weight (A-operand) tiles of the v3 / stem / tconv3 / sconv9 loops.  The MFMA rows of a weight fragment are the permuted
+// couts perm_row(odd, fr) = {0-3, 8-11, 16-19, 24-27} (+ 4 for the odd fragment): under the (r & 7) key rows 0-3 and
+// 24-27 (and 8-11 / 16-19) of one ds_read_b128 lane group ({0-3, 12-15, 20-27}, ... - MI355X_MICROARCH.md, LDS) fall on
+// the same 16-byte slots of the 256-byte bank row, a 2-way conflict on every weight fragment read.  Row bits (0, 1, 3)
+// as the key put the 16 lanes of every group on 16 different slots - for these rows and for consecutive rows alike.
+__device__ __forceinline__ int a_key(int r) { return (r & 3) | ((r >> 1) & 4); }
+__device__ __forceinline__ int lds_off_a(int r, int chunk) { return r * 128 + ((chunk ^ a_key(r)) << 4); }
+// source-side chunk of lane `lane` of wave `wave` loading weight row (8 wave' + (lane >> 3)), wave' = wave (mod 2)
+__device__ __forceinline__ int a_kseg(int wave, int lane) { return (lane & 7) ^ (((lane >> 3) & 3) | ((wave & 1) << 2)); }
 
 // ---------------------------------------------------------------------------------------------
 // v2 main kernel: both operands go HBM/L2 -> LDS with 16-byte LDS-DMA loads (no register staging, no
@@ -585,6 +594,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
 
   const int lrow = wave * 8 + (lane >> 3);
   const int kseg = (lane & 7) ^ (lane >> 3);
+  const int kseg_a = a_kseg(wave, lane);
 
   const int ksteps_all = (p.Ktot + BK - 1) / BK;
   const int ks_begin = kslice * p.ks_per;
@@ -594,6 +604,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   // K tail: only dense problems reach here with Ktot % 64 != 0; the tail K-step is the global last one
   const bool has_tail = DENSE && (p.Ktot & (BK - 1)) != 0 && (ks_begin + ksteps == ksteps_all);
   const bool lane_tail = (ksteps_all - 1) * BK + kseg * 8 >= p.Ktot;
+  const bool lane_tail_a = (ksteps_all - 1) * BK + kseg_a * 8 >= p.Ktot;
 
   const char* ap[WM];
   int a_step = 2 * BK;     // bytes a weight pointer advances per K-step
@@ -610,7 +621,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
-      ap[i] = reinterpret_cast<const char*>(gw + (long long)row * p.ldw + klin0);
+      ap[i] = reinterpret_cast<const char*>(gw + (long long)row * p.ldw + kbase + kseg_a * 8);
     }
   }
   const char* bp[WN];
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
     char* b = a + A_BYTES;
     if (tail) {   // dense only: lanes past the end of K read zeros
 #pragma unroll
-      for (int i = 0; i < WM; ++i) glds16(lane_tail ? zero : ap[i], a + i * 4096);
+      for (int i = 0; i < WM; ++i) glds16(lane_tail_a ? zero : ap[i], a + i * 4096);
 #pragma unroll
       for (int i = 0; i < WN; ++i) glds16(lane_tail ? zero : bp[i], b + i * 4096);
       return;
@@ -750,7 +761,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
   for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
-      aoffs[odd][s2] = lds_off(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
+      aoffs[odd][s2] = lds_off_a(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) boffs[s2] = A_BYTES + lds_off(wn * (16 * WN) + fr, s2 * 4 + fq);
 
@@ -928,7 +939,7 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
   }
   // ---- weights ring
   const int lrow = wave * 8 + (lane >> 3);
-  const int kseg = (lane & 7) ^ (lane >> 3);
+  const int kseg = a_kseg(wave, lane);
   const char* ap[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
 #pragma unroll
   for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = ST_PATCH + lds_off(wm * 32 + perm_row(odd, fr), s2 * 4 + fq);
+    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = ST_PATCH + lds_off_a(wm * 32 + perm_row(odd, fr), s2 * 4 + fq);
   const int lane_b = wn * (16 * ST_ROWB) + (fr + fq) * 16;
 
 #pragma unroll
@@ -1378,7 +1389,7 @@ __global__ __launch_bounds__(256) void tconv3_bf16_kernel(const IgemmParams p) {
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int row = min(cout0 + lrow + 32 * i, p.Cout - 1);
-    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + kseg * 8);
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + a_kseg(wave, lane) * 8);
   }
   const char* bp[WN];
 #pragma unroll
@@ -1417,7 +1428,7 @@ __global__ __launch_bounds__(256) void tconv3_bf16_kernel(const IgemmParams p) {
 #pragma unroll
   for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = lds_off(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
+    for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = lds_off_a(wm * (16 * WM) + perm_row(odd, fr), s2 * 4 + fq);
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) boffs[s2] = lds_off(wn * 64 + fr, s2 * 4 + fq);
 
@@ -1553,7 +1564,7 @@ __global__ __launch_bounds__(256 * KG) void sconv9_bf16_kernel(const IgemmParams
 #pragma unroll
   for (int i = 0; i < AL; ++i) {
     const int row = min(cout0 + (wave + NWAVE * i) * 8 + (lane >> 3), p.Cout - 1);
-    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + kseg * 8);
+    ap[i] = reinterpret_cast<const char*>(p.w + (long long)row * p.ldw + a_kseg(wave, lane) * 8);
   }
   const uint16_t* frame = p.in + (long long)(f / p.To) * p.in_n_stride + (long long)(f % p.To) * p.Hi * p.Wi * p.pix;
   const char* bp[NI];
@@ -1596,7 +1607,7 @@ __global__ __launch_bounds__(256 * KG) void sconv9_bf16_kernel(const IgemmParams
 #pragma unroll
   for (int odd = 0; odd < 2; ++odd)
 #pragma unroll
-    for (int h = 0; h < NS2; ++h) aoffs[odd][h] = lds_off(wm * (16 * WM) + perm_row(odd, fr), (kg * NS2 + h) * 4 + fq);
+    for (int h = 0; h < NS2; ++h) aoffs[odd][h] = lds_off_a(wm * (16 * WM) + perm_row(odd, fr), (kg * NS2 + h) * 4 + fq);
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll

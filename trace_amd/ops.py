@@ -422,14 +422,15 @@ EPI_WTILED = 64
 def tile_weights(w):
     """(N, K) bf16 row-major -> the pre-tiled layout of TRACE_EPI_WTILED (N % 128 == 0, K % 64 == 0): same
     shape / bytes, blocks [N/128][K/64] of 128 rows x 64 k with the 16-byte chunks of row r stored at chunk
-    position pc holding logical chunk pc ^ (r & 7)."""
+    position pc holding logical chunk pc ^ a_key(r), a_key(r) = bits (0, 1, 3) of r (csrc/igemm.hip: the swizzle that
+    keeps the weight fragment reads free of LDS bank conflicts)."""
     N, K = w.shape
     if N % 128 or K % 64 or w.dtype != torch.bfloat16:
         raise RuntimeError("tile_weights: needs bf16 (N % 128 == 0, K % 64 == 0)")
     t = w.view(N // 128, 128, K // 64, 8, 8).permute(0, 2, 1, 3, 4)          # [nt][kt][r][chunk][8]
     r = torch.arange(128, device=w.device).view(128, 1)
     pc = torch.arange(8, device=w.device).view(1, 8)
-    src = (pc ^ (r & 7)).view(1, 1, 128, 8, 1).expand(N // 128, K // 64, 128, 8, 8)
+    src = (pc ^ ((r & 3) | ((r >> 1) & 4))).view(1, 1, 128, 8, 1).expand(N // 128, K // 64, 128, 8, 8)
     return torch.gather(t, 3, src).contiguous().view(N, K)
 
 
