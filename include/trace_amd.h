@@ -107,7 +107,8 @@ int trace_nms(const float* boxes, const float* scores, int N, float thresh,
 /* Per-class NMS of one image in ONE pass — lib/modeling_rel/model_builder_rel.py:1286-1313
  * (the `for j in range(1, num_classes)` loop around box_utils.nms): boxes of different `group`
  * (class) never suppress each other; within a group the result equals trace_nms on that group's
- * boxes alone.  keep_out: kept ORIGINAL indices ascending. */
+ * boxes alone.  keep_out: kept ORIGINAL indices ascending.  Group ids must lie in [0, 2^18 - 2] (class ids): the
+ * boxes are sorted by (group, score) so that the groups are reduced side by side, one short chain each. */
 int trace_nms_grouped(const float* boxes, const float* scores, const int32_t* group,
                       int N, float thresh, int mode, int64_t* keep_out,
                       int32_t* num_keep, void* workspace, size_t workspace_bytes,

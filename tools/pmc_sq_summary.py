@@ -14,7 +14,7 @@ from collections import defaultdict
 CLASSES = (("igemm3", "igemm3_bf16_kernel"), ("igemm2", "igemm2_bf16_kernel"), ("tconv3", "tconv3_bf16_kernel"),
            ("sconv9", "sconv9_bf16_kernel"), ("stem16", "stem16_bf16_kernel"), ("splitk_reduce", "igemm_splitk_reduce"),
            ("roi_align_mfma", "roi_align_fwd_mfma"), ("roi_align_avg", "roi_align_avg"), ("pair_pool", "pair_pool_kernel"),
-           ("pair_combine", "pair_combine_kernel"), ("pair_infer", "pair_infer_kernel"), ("tree_gru", "tree_gru"),
+           ("pair_combine", "pair_combine_kernel"), ("pair_infer", "pair_infer_kernel"), ("pair_mfma", "pair_mfma_kernel"), ("rank_clip", "rank_clip_topk"), ("tree_gru", "tree_gru"),
            ("nms_reduce", "nms_reduce"), ("nms_mask", "nms_mask"), ("nms_sort", "nms_sort"))
 
 tot = defaultdict(lambda: defaultdict(float))

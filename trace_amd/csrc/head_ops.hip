@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) void pair_combine_kernel(
 // with 8 consecutive channels of a cell -> 16-byte stores) and all 64 cell columns: 24 accumulator tiles.
 // ---------------------------------------------------------------------------
 constexpr int PM_LDP = 224;        // pixel pitch of vabT (>= H * W rounded up to 8, + 24)
-constexpr int PM_WROW = PM_LDP + 8;  // weight image row (elements): 464 B, rows 16 B apart mod 128 B
+constexpr int PM_WROW = PM_LDP + 48; // weight image row (elements): 544 B = 32 B mod the 256-B bank row, so the 16 lanes of a ds_read_b128 group (8 cells of one k quad + 8 of the next) fall on 16 different slots
 constexpr int PM_THREADS = 256;
 typedef __attribute__((ext_vector_type(8))) short pm_s8;
 typedef __attribute__((ext_vector_type(4))) float pm_f4;

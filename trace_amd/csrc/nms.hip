@@ -73,10 +73,13 @@ static size_t carve(int N, void* base, NmsWorkspace* ws) {
 
 // Sort key: "a sorts before b" (descending score, ties by ascending original index) == key(a) > key(b).
 // -0.0f sorts with +0.0f (the float comparison of the reference treats them as equal, then the index decides).
-__device__ __forceinline__ uint64_t sort_key(float score, int index) {
+// Grouped NMS sorts by group first (ascending id, 18 bits: ids in [0, 2^18 - 2]), so that every group is one contiguous
+// run of the sorted order and the groups can be reduced independently; group 0 everywhere gives the plain order.
+// index < NMS_MAX_BOXES = 2^14.
+__device__ __forceinline__ uint64_t sort_key(float score, int index, int group = 0) {
   uint32_t u = __float_as_uint(score + 0.0f);
   u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
-  return ((uint64_t)u << 32) | (uint32_t)(~index);
+  return ((uint64_t)(0x3ffffu - ((uint32_t)group & 0x3ffffu)) << 46) | ((uint64_t)u << 14) | (uint32_t)(0x3fff - index);
 }
 
 // Rank sort: position of box i in the sorted order = number of boxes that sort before it.  N^2 integer comparisons
@@ -95,13 +98,13 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   __shared__ int part[16][64];
   const int lane = threadIdx.x & 63, split = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
-  const uint64_t ki = sort_key(i < N ? scores[i] : 0.f, i);
+  const uint64_t ki = sort_key(i < N ? scores[i] : 0.f, i < N ? i : 0, (group && i < N) ? group[i] : 0);
   int cnt = 0;
   for (int t0 = 0; t0 < N; t0 += NMS_SORT_TILE) {
     const int tn = min(NMS_SORT_TILE, N - t0);
     __syncthreads();
     // key 0 (below every real key: real keys have the index complement in the low word) pads the tile to 32 keys per wave
-    for (int j = threadIdx.x; j < NMS_SORT_TILE; j += blockDim.x) keys[j] = j < tn ? sort_key(scores[t0 + j], t0 + j) : 0ULL;
+    for (int j = threadIdx.x; j < NMS_SORT_TILE; j += blockDim.x) keys[j] = j < tn ? sort_key(scores[t0 + j], t0 + j, group ? group[t0 + j] : 0) : 0ULL;
     __syncthreads();
     const int per = ((tn + 15) / 16 + 1) & ~1;   // keys per wave, even
     const int j0 = split * per, j1 = min(j0 + per, NMS_SORT_TILE);
@@ -137,10 +140,13 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sboxes,
                                                       const float* __restrict__ sareas, int N,
                                                       int col_blocks, float thresh, int mode,
-                                                      const int32_t* __restrict__ sgroup,
+                                                      const int32_t* __restrict__ sgroup, int grouped,
                                                       uint64_t* __restrict__ mask) {
   const int row_blk = blockIdx.y, col_blk = blockIdx.x;
   if (col_blk < row_blk) return;
+  // grouped: the boxes are sorted by group, so a column block whose first group lies behind the row block's last one
+  // shares no group with it; nms_reduce_grouped_kernel never reads such a word
+  if (grouped && sgroup[col_blk * 64] > sgroup[min(row_blk * 64 + 63, N - 1)]) return;
   __shared__ float4 cb[64];
   __shared__ float ca[64];
   __shared__ int cg[64];
@@ -297,6 +303,68 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
   }
 }
 
+// Grouped NMS (one call for all classes: box_results_with_nms_and_limit, core/test.py:862-879): groups are contiguous
+// runs of the sorted order and never interact, so they are reduced in parallel.  Workgroup b (one wave) owns the groups
+// that START inside block b - the positions from its first start up to the first start in a later block - and walks
+// only their blocks with the resolve of nms_reduce_kernel; kept boxes OR their words for the later blocks that can still
+// hold their group into a bitmap in LDS.  35 classes x <= 300 boxes: chains of <= 5-6 blocks instead of one of 80.
+__global__ __launch_bounds__(64) void nms_reduce_grouped_kernel(const uint64_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ order,
+                                                                const int32_t* __restrict__ sgroup, int N, int col_blocks,
+                                                                int32_t* __restrict__ keep) {
+  __shared__ unsigned long long remv[NMS_MAX_BOXES / 64];
+  const int lane = threadIdx.x, b = blockIdx.x;
+  auto starts = [&](int blk) {   // lanes whose box opens a group
+    const int p = blk * 64 + lane;
+    const bool st = p < N && (p == 0 || sgroup[p - 1] != sgroup[p]);
+    return (uint64_t)__ballot(st);
+  };
+  const uint64_t s0 = starts(b);
+  if (!s0) return;
+  for (int i = lane; i < NMS_MAX_BOXES / 64; i += 64) remv[i] = 0ULL;
+  __syncthreads();
+  uint64_t own = ~0ULL << __builtin_ctzll(s0);   // lanes of the current block that belong to this workgroup's groups
+  for (int it = b; it < col_blocks; ++it) {
+    bool last = false;
+    if (it > b) {
+      const uint64_t st = starts(it);
+      own = ~0ULL;
+      if (st) {
+        const int e = __builtin_ctzll(st);
+        if (e == 0) break;
+        own = (1ULL << e) - 1ULL;
+        last = true;
+      }
+    }
+    const int row = it * 64 + lane;
+    const int rows_here = min(N - it * 64, 64);
+    const uint64_t valid = rows_here >= 64 ? ~0ULL : ((1ULL << rows_here) - 1ULL);
+    own &= valid;
+    const uint64_t word = mask[(size_t)row * col_blocks + it];
+    const uint64_t in = word & ((1ULL << lane) - 1ULL);
+    uint64_t R = remv[it] | ~own, K = 0;
+    for (;;) {
+      const uint64_t und = ~(R | K);
+      if (!und) break;
+      const bool mine = (und >> lane) & 1ULL;
+      const bool rm = mine && (in & K) != 0;
+      const bool kp = mine && !rm && (in & ~R) == 0;
+      K |= __ballot(kp);
+      R |= __ballot(rm);
+    }
+    if ((own >> lane) & 1ULL) keep[order[row]] = (int)((K >> lane) & 1ULL);
+    if (last || rows_here < 64) break;
+    if ((K >> lane) & 1ULL) {
+      const int g = sgroup[row];
+      for (int c = it + 1; c < col_blocks && sgroup[c * 64] <= g; ++c) {
+        const uint64_t w = mask[(size_t)row * col_blocks + c];
+        if (w) atomicOr(&remv[c], (unsigned long long)w);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // keep flags (by original index) -> ascending index list + count.
 __global__ __launch_bounds__(1024) void nms_compact_kernel(const int32_t* __restrict__ keep, int N,
                                                            int64_t* __restrict__ keep_out,
@@ -355,8 +423,11 @@ static int nms_launch(const float* boxes, const float* scores, const int32_t* gr
   hipLaunchKernelGGL(nms_sort_kernel, dim3(col_blocks), dim3(1024), 0, s, boxes, scores, N, npad, ws.order, ws.sboxes,
                      ws.sareas, group, ws.sgroup);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(col_blocks, col_blocks), dim3(64), 0, s, ws.sboxes,
-                     ws.sareas, N, col_blocks, thresh, mode, ws.sgroup, ws.mask);
-  if (col_blocks <= 128 + 1 + NMS_CARRY)
+                     ws.sareas, N, col_blocks, thresh, mode, ws.sgroup, group ? 1 : 0, ws.mask);
+  if (group)
+    hipLaunchKernelGGL(nms_reduce_grouped_kernel, dim3(col_blocks), dim3(64), 0, s, ws.mask, ws.order, ws.sgroup, N,
+                       col_blocks, ws.keep);
+  else if (col_blocks <= 128 + 1 + NMS_CARRY)
     hipLaunchKernelGGL(nms_reduce_kernel<2>, dim3(1), dim3(1024), 0, s, ws.mask, ws.order, N, col_blocks, ws.keep);
   else
     hipLaunchKernelGGL(nms_reduce_kernel<4>, dim3(1), dim3(1024), 0, s, ws.mask, ws.order, N, col_blocks, ws.keep);
