@@ -65,7 +65,14 @@ class PackedLinears(nn.Module):
     """Mixin: Linear / 1x1-conv layers as operands of the bf16 MFMA GEMM (weights packed once: bf16, K padded to 8,
     N padded to 8, optional column permutation to the channels-last pooled order, several layers stacked along N).
     A packed entry remembers (data_ptr, version) of the tensors it was built from and is rebuilt when they change
-    (state-dict load, device move, in-place edit) - whichever module the load went through."""
+    (state-dict load, device move, in-place edit) - whichever module the load went through.  Edits through `.data`
+    (`p.data.copy_()`, `p.data.uniform_()`) do not bump the version counter and are NOT seen: write parameters under
+    `torch.no_grad()` (`p.copy_()`), as trace_amd.synthetic does, or call `drop_packed()`."""
+
+    def drop_packed(self):
+        """Forget every packed weight (and invalidate captured graphs that hold them): after edits through `.data`."""
+        self._pk_store().clear()
+        self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
 
     def _pk_store(self):
         d = self.__dict__.get("_pk")
@@ -158,7 +165,10 @@ class PackedLinears(nn.Module):
             w, b, n = store[tkey][0]
             kw["b_tiled"] = True
         else:
-            w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)
+            stale = tkey in store                       # rebuilt after a weight change: the old tiled copy may be
+            w, b, n = self._lin_w(key, layers, perm_hw_c, pad_bias)   # baked into captured step graphs
+            if stale:
+                self._pk_epoch = getattr(self, "_pk_epoch", 0) + 1
             if tiled and w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0:
                 w = ops.tile_weights(w)
                 store[tkey] = ((w, b, n), self._sig(self._layer_deps(layers)))

@@ -15,6 +15,7 @@ the packed weights.  Inference only (the reference evaluates with
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.utils import _ntuple, _triple
 
 from . import ops
@@ -82,6 +83,26 @@ class ConvModule(nn.Module):
         return ops.conv3d(x, w, b, c.kernel_size, c.stride, c.padding, c.dilation, residual=residual, relu=relu,
                           pool_t2=pool_t2)
 
+    def run_train(self, x, relu=None):
+        """`run` under autograd (trace_amd/autograd.py): the BatchNorm fold is taken differentiably from the f32
+        parameters (frozen statistics: running_mean / running_var are constants), the convolution and both of its
+        gradients run on the HIP kernels.  Gradients reach conv.weight, conv.bias, bn.weight, bn.bias and x."""
+        from . import autograd as tag
+        w = self.conv.weight.float()
+        cout = w.shape[0]
+        if self.with_norm:
+            scale = self.bn.weight.float() / torch.sqrt(self.bn.running_var.float() + self.bn.eps)
+            shift = self.bn.bias.float() - self.bn.running_mean.float() * scale
+            w = w * scale.view(-1, 1, 1, 1, 1)
+            if self.conv.bias is not None:
+                shift = shift + self.conv.bias.float() * scale
+        else:
+            shift = self.conv.bias.float() if self.conv.bias is not None else None
+        wf = w.permute(0, 2, 3, 4, 1).reshape(cout, -1)
+        c = self.conv
+        relu = self.with_activation if relu is None else relu
+        return tag.conv3d(x, wf, shift, c.kernel_size, c.stride, c.padding, c.dilation, relu=relu)
+
     def _apply(self, fn, *a, **k):
         self._packed = None
         _PACK_EPOCH[0] += 1
@@ -134,6 +155,31 @@ class NonLocal3d(nn.Module):
         pw = pw / pw.shape[-1]
         y = torch.matmul(pw, g_x).permute(0, 2, 1).contiguous().reshape(n, c, *x.size()[2:])
         return x + self.conv_out(y)
+
+    def run_train(self, x):
+        """The block under autograd: the four 1x1x1 convs and the two products (S = phi^T g per clip, y = theta S / N_kv -
+        dot_product mode has no softmax) and all their gradients on the HIP kernels (trace_amd/autograd.py); the
+        (1,2,2) max-pool of phi / g and the per-clip transposes are torch ops."""
+        from . import autograd as tag
+        N, T, H, W, C = x.shape
+        c = self.inter_channels
+        nq = T * H * W
+        theta = self.theta.run_train(x).reshape(N, nq, c)
+        phi = self._conv(self.phi).run_train(x)
+        g = self._conv(self.g).run_train(x)
+        if self.sub_sample:
+            pool = lambda t: F.max_pool3d(t.permute(0, 4, 1, 2, 3), (1, 2, 2)).permute(0, 2, 3, 4, 1)
+            phi, g = pool(phi), pool(g)
+        nkv = phi.shape[1] * phi.shape[2] * phi.shape[3]
+        nkp = (nkv + 7) // 8 * 8
+        phiT = F.pad(phi.reshape(N, nkv, c).transpose(1, 2), (0, nkp - nkv))      # (N, c, nkp): zero columns add nothing
+        gT = F.pad(g.reshape(N, nkv, c).transpose(1, 2), (0, nkp - nkv))
+        ys = []
+        for n in range(N):
+            S = tag.gemm_nt(phiT[n].contiguous(), gT[n].contiguous())                 # (c, c): S[i][j] = sum_kv phi[kv][i] g[kv][j]
+            ys.append(tag.gemm_nt(theta[n], (S.float() / nkv).t().contiguous()))      # (nq, c)
+        y = torch.stack(ys, 0).view(N, T, H, W, c)
+        return x + self.conv_out.run_train(y, relu=False)
 
     def _tpg_packed(self):
         """theta | phi | g stacked along the output channels: one GEMM instead of three."""
@@ -278,6 +324,14 @@ class Bottleneck3d(nn.Module):
             if pool_t2:
                 out = ops.maxpool3d(out, (2, 1, 1), (2, 1, 1))
         return out
+
+    def run_train(self, x):
+        """The block under autograd (lib/i3d/resnet3d.py:292-318 with frozen BN statistics): every conv and its two
+        gradients on the HIP kernels, residual add + ReLU as torch elementwise ops on the bf16 stream."""
+        identity = x if self.downsample is None else self.downsample.run_train(x)
+        out = self.conv3.run_train(self.conv2.run_train(self.conv1.run_train(x)))
+        out = torch.relu(out + identity)
+        return self.non_local_block.run_train(out) if self.non_local else out
 
     @staticmethod
     def _twin(res, shape):
@@ -463,6 +517,29 @@ class ResNet3d(nn.Module):
                         ops.PROBE.append(("%s.%d" % (name, bi), x))
                 if stage_hook is not None and stage_hook[0] == i:
                     stage_hook[1]()
+        return x
+
+    def forward_train(self, x, in_ntchw=False):
+        """Training-side forward (tools/train_net_step_rel.py:580-629 reaches the backbone through
+        Generalized_RCNN._forward): the stem and the stages up to `frozen_stages` (lib/i3d/resnet3d.py:746-767) run on the
+        inference path without a graph, the later stages run under autograd with every conv / GEMM and its gradients on
+        the HIP kernels (`run_train`).  BatchNorm uses its running statistics everywhere (norm_eval semantics; batch
+        statistics - the reference config's norm_eval=False - are not implemented).  -> (N,T',H',W',feat_dim) bf16."""
+        frozen = max(self.frozen_stages, 0)
+        with torch.no_grad():
+            x = self._run_stem(x, in_ntchw)
+        for i, name in enumerate(self.res_layers[:self.num_stages]):
+            blocks = list(getattr(self, name))
+            if i < frozen:
+                with torch.no_grad():
+                    for bi, blk in enumerate(blocks):
+                        blk.res_f32 = False
+                        x = blk.run(x, pool_t2=(i == 0 and self.with_pool2 and bi == len(blocks) - 1))
+            else:
+                for blk in blocks:
+                    x = blk.run_train(x)
+                if i == 0 and self.with_pool2:
+                    x = F.max_pool3d(x.permute(0, 4, 1, 2, 3), (2, 1, 1), (2, 1, 1)).permute(0, 2, 3, 4, 1).contiguous()
         return x
 
     def out_frames(self, T):

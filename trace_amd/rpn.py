@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import boxes as box_ops
-from . import ops
+from . import _C, ops
 from .resnet3d import _PACK_EPOCH
 
 
@@ -88,6 +88,10 @@ class GenerateProposalsOp(nn.Module):
         props, sc = props[keep], sc[keep]
         # 6./7. NMS (Cython semantics: >= thresh, ascending indices = descending score here) and the post-NMS cut (:161-171)
         if self.nms_thresh > 0:
+            if props.shape[0] > _C.NMS_MAX_BOXES:
+                raise RuntimeError("generate_proposals: %d candidates reach NMS with pre_nms_topN = %d (<= 0 keeps every "
+                                   "anchor); the device NMS holds %d - set RPN_PRE_NMS_TOP_N (the reference's configs use "
+                                   "6000 / 12000)" % (props.shape[0], self.pre_nms_topN, _C.NMS_MAX_BOXES))
             k = box_ops.nms(torch.cat([props, sc[:, None]], 1), self.nms_thresh)
             if self.post_nms_topN > 0:
                 k = k[:self.post_nms_topN]

@@ -32,16 +32,22 @@ def randomize_model(model, seed=1, calib_clip=None, bn_calibrate=None):
     """Seeded BN affine params + freq-bias table ~ log U(1e-3,1).  `bn_calibrate`
     (test/bench infrastructure) may replace the backbone state dict with calibrated BN statistics."""
     g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():   # in-place writes that bump the version counters the packed-weight caches watch
+        _randomize(model, g)
+    return model
+
+
+def _randomize(model, g):
     for name, mod in model.named_modules():
         if isinstance(mod, torch.nn.BatchNorm3d):
             lo, hi = (0.2, 0.5) if (name.endswith("conv3.bn") or "conv_out" in name) else (0.7, 1.3)
-            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) * (hi - lo) + lo)
-            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.weight.copy_(torch.rand(mod.num_features, generator=g) * (hi - lo) + lo)
+            mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
             mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
             mod.running_var.copy_(torch.rand(mod.num_features, generator=g) * 0.5 + 0.75)
     if hasattr(model, "freq_bias"):
         tab = model.freq_bias.rel_baseline.weight
-        tab.data.copy_(torch.log(torch.rand(tab.shape, generator=g) * (1 - 1e-3) + 1e-3))
+        tab.copy_(torch.log(torch.rand(tab.shape, generator=g) * (1 - 1e-3) + 1e-3))
     return model
 
 
