@@ -63,9 +63,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
+def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0, min_s=12.0):
     """CPU oracle ("port" of the reference path: oracle/i3d_ref.py + oracle/head_ref.py, fp32) on a
-    bounded sample of the same workload: whole clips, one at a time as the reference does."""
+    bounded sample of the same workload: whole clips, one at a time as the reference does, cycling through the step's
+    clips until at least `min_s` seconds of CPU work are done (and stopping at `budget_s`)."""
     from oracle.i3d_ref import i3d_forward
     from oracle.head_ref import head_forward
     torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
@@ -73,8 +74,8 @@ def cpu_baseline(model_sd, frames, blob, feat, rois, budget_s=25.0):
     i3d_sd = {k[len("Prd_RCNN."):]: v for k, v in model_sd.items() if k.startswith("Prd_RCNN.")}
     done, t0 = 0, time.time()
     with torch.no_grad():
-        while done < frames.shape[0] and (done == 0 or time.time() - t0 < budget_s):
-            b = done
+        while done == 0 or (time.time() - t0 < budget_s and (done < frames.shape[0] or time.time() - t0 < min_s)):
+            b = done % frames.shape[0]
             tm = i3d_forward(i3d_sd, frames[b:b + 1].permute(0, 2, 1, 3, 4).contiguous())   # (1,C,T',h,w)
             head_forward(model_sd, blob[b:b + 1], feat[b:b + 1], tm[0].permute(1, 0, 2, 3).contiguous(), rois[b])
             done += 1

@@ -597,11 +597,9 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
     const float* __restrict__ bias_ab, float scale, int PS, uint16_t* __restrict__ sp) {
   __shared__ __attribute__((aligned(16))) uint16_t wimg[64 * PM_WROW];
   __shared__ float wy[8][16], wx[8][16], sy[8], sx[8];
-  __shared__ int ylo[8], yhi[8];
+  __shared__ int ylo[8], yhi[8], xlo[8], xhi[8];   // pixels with a non-zero weight, per bin and axis (lo > hi: none)
   __shared__ float qrow[4][PM_LDP];
-  __shared__ float rsc[4][16][8];      // x-pooled scalar maps: [which][y][cx]
   __shared__ float prob[4][64];        // pooled scores, then softmax weights: [2 pair + (s | o)][cell]
-  __shared__ unsigned char chy[PM_LDP / 8], chx[PM_LDP / 8];   // (y, x) of the first pixel of every 8-pixel chunk
   __shared__ __attribute__((aligned(16))) float bias_l[4][512];   // map bias of V | W_A V | W_B V, then b_A + b_B  (D <= 512)
   const int tid = threadIdx.x;
   const int cells = PS * PS;
@@ -655,19 +653,18 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
       last = max(last, hi);
     }
     (axis ? sx : sy)[b] = tot;
-    if (!axis) {
-      ylo[b] = first;
-      yhi[b] = last;
-    }
+    (axis ? xlo : ylo)[b] = first;
+    (axis ? xhi : yhi)[b] = last;
+  }
+  // the weight image starts as zeros: a cell touches at most (grid + 1)^2 of its <= 224 pixels
+  {
+    const int cell = tid & 63;
+    for (int c8 = tid >> 6; c8 < PM_LDP / 8; c8 += PM_THREADS / 64)
+      *reinterpret_cast<uint4*>(&wimg[cell * PM_WROW + 8 * c8]) = make_uint4(0, 0, 0, 0);
   }
   for (int i = tid; i < 4 * D; i += PM_THREADS) {
     const int mt = i / D, c = i - mt * D;
     bias_l[mt][c] = mt < 3 ? (vbias ? vbias[i] : 0.f) : bias_ab[c];
-  }
-  if (tid < PM_LDP / 8) {
-    const int y = (8 * tid) / W;
-    chy[tid] = (unsigned char)min(y, 15);
-    chx[tid] = (unsigned char)(8 * tid - y * W);
   }
   // ---- the queries' scalar maps of this clip (rows 2 i = q_s of object i, 2 i + 1 = q_o), zero behind the map
   {
@@ -694,73 +691,13 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
     }
   const int k0 = ymax < 0 ? 0 : ((ymin * W) & ~7);
   const int ksteps = ymax < 0 ? 0 : ((ymax + 1) * W - k0 + 31) >> 5;
-  // ---- scores, stage 1: the scalar maps pooled along x, items (which, y, cx)
-  for (int it = tid; it < 4 * 16 * 8; it += PM_THREADS) {
-    const int which = it >> 7, y = (it >> 3) & 15, cx = it & 7;
-    float r = 0.f;
-    if (which < 2 * npair && y < H && cx < PS) {
-      const float* qr = &qrow[which][y * W];
-#pragma unroll
-      for (int x = 0; x < 16; ++x) r += wx[cx][x] * qr[x];      // wx is 0 from x = W on; qr stays inside the zero-filled row
-    }
-    rsc[which][y][cx] = r;
-  }
-  // ---- weight image: [cell][k0 + 32 ksteps) bf16, eight pixels per item
-  {
-    const int chunks = ksteps * 4;
-    const int cbase = k0 >> 3;
-    const int cell = tid & 63;
-    const int cy = cell / PS, cx = cell - cy * PS;
-    for (int c8 = tid >> 6; c8 < chunks; c8 += PM_THREADS / 64) {
-      uint4 o = make_uint4(0, 0, 0, 0);
-      if (cell < cells) {
-        int y = chy[cbase + c8], x = chx[cbase + c8];
-        float w8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          w8[j] = y < H ? wy[cy][y] * wx[cx][x] : 0.f;
-          if (++x == W) {
-            x = 0;
-            ++y;
-          }
-        }
-        o.x = pack_bf16x2(w8[0], w8[1]);
-        o.y = pack_bf16x2(w8[2], w8[3]);
-        o.z = pack_bf16x2(w8[4], w8[5]);
-        o.w = pack_bf16x2(w8[6], w8[7]);
-      }
-      *reinterpret_cast<uint4*>(&wimg[cell * PM_WROW + 8 * c8]) = o;
-    }
-  }
-  __syncthreads();
-  // ---- scores, stage 2 (along y) and the softmax over the cells: wave `which`, lane = cell
-  {
-    const int which = tid >> 6, cell = tid & 63;
-    if (which < 2 * npair) {
-      float a = -__builtin_inff();
-      if (cell < cells) {
-        const int cy = cell / PS, cx = cell - cy * PS;
-        a = 0.f;
-#pragma unroll
-        for (int y = 0; y < 16; ++y) a += wy[cy][y] * rsc[which][y][cx];
-      }
-      float mx = a;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-      const float e = cell < cells ? expf(a - mx) : 0.f;
-      float ss = e;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
-      prob[which][cell] = e / ss;
-    }
-  }
-  __syncthreads();
-
+  // ---- the first K-step's A fragments of this wave's first channel group: in flight while the image is built
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kg = lane >> 4;
-  for (int cb = wave * 32; cb < D; cb += (PM_THREADS / 64) * 32) {
+  const uint16_t* arow[3][2];
+  pm_s8 af[2][3][2];
+  auto set_rows = [&](int cb) {
     // A rows: tile t of the wave's pair of 16-row tiles holds channels cb + 8 (m >> 2) + 4 t + (m & 3), m = li
-    const uint16_t* arow[3][2];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
@@ -768,6 +705,55 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
         const int ch = cb + 8 * (li >> 2) + 4 * t + (li & 3);
         arow[mt][t] = vabT + ((long long)(g.batch * 3 + mt) * D + ch) * PM_LDP + k0 + 8 * kg;
       }
+  };
+  auto load_step = [&](int set, int ks) {
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) af[set][mt][t] = *reinterpret_cast<const pm_s8*>(arow[mt][t] + 32 * ks);
+  };
+  if (wave * 32 < D) {
+    set_rows(wave * 32);
+    if (ksteps > 0) load_step(0, 0);
+  }
+  // ---- weight image [cell][pixel - k0] (bf16) and pooled scores, both over the cell's non-zero pixels only:
+  // thread (part = tid >> 6, cell = tid & 63).  Image: part takes every fourth of the cell's pixel rows.  Scores: part =
+  // which (2 pair + (s | o)), then the softmax over the cells with lane = cell.
+  {
+    const int part = tid >> 6, cell = tid & 63;
+    float a = -__builtin_inff();
+    if (cell < cells) {
+      const int cy = cell / PS, cx = cell - cy * PS;
+      const int y0 = ylo[cy], y1 = yhi[cy], x0 = xlo[cx], x1 = xhi[cx];
+      for (int y = y0 + part; y <= y1; y += PM_THREADS / 64) {
+        const float wyv = wy[cy][y];
+        uint16_t* dst = &wimg[cell * PM_WROW + y * W - k0];
+        for (int x = x0; x <= x1; ++x) dst[x] = f32_to_bf16(wyv * wx[cx][x]);
+      }
+      if (part < 2 * npair) {
+        a = 0.f;
+        for (int y = y0; y <= y1; ++y) {
+          const float* qr = &qrow[part][y * W];
+          float r = 0.f;
+          for (int x = x0; x <= x1; ++x) r += wx[cx][x] * qr[x];
+          a += wy[cy][y] * r;
+        }
+      }
+    }
+    if (part < 2 * npair) {
+      float mx = a;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+      const float e = cell < cells ? expf(a - mx) : 0.f;
+      float ss = e;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+      prob[part][cell] = e / ss;
+    }
+  }
+  __syncthreads();
+
+  for (int cb = wave * 32; cb < D; cb += (PM_THREADS / 64) * 32) {
     pm_f4 acc[3][2][4];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt)
@@ -776,14 +762,8 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) acc[mt][t][nf] = pm_f4{0.f, 0.f, 0.f, 0.f};
     // the NEXT K-step's fragments are loaded before this step's 24 MFMAs (two register sets): an L2 round trip hides
-    // behind the matrix work of this wave and of the other workgroup on the CU
-    pm_s8 af[2][3][2];
-    auto load_step = [&](int set, int ks) {
-#pragma unroll
-      for (int mt = 0; mt < 3; ++mt)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) af[set][mt][t] = *reinterpret_cast<const pm_s8*>(arow[mt][t] + 32 * ks);
-    };
+    // behind the matrix work of this wave and of the other workgroup on the CU; step 0 of a channel group is loaded
+    // before the previous group's epilogue (before the image build for the first group)
     auto mma_step = [&](int set, int ks) {
       pm_s8 bf[4];
 #pragma unroll
@@ -797,7 +777,6 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
           for (int t = 0; t < 2; ++t)
             acc[mt][t][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[set][mt][t], bf[nf], acc[mt][t][nf], 0, 0, 0);
     };
-    if (ksteps > 0) load_step(0, 0);
     for (int ks = 0; ks < ksteps; ks += 2) {
       if (ks + 1 < ksteps) load_step(1, ks + 1);
       mma_step(0, ks);
@@ -805,6 +784,10 @@ __global__ __launch_bounds__(PM_THREADS, 2) void pair_mfma_kernel(
         if (ks + 2 < ksteps) load_step(0, ks + 2);
         mma_step(1, ks + 1);
       }
+    }
+    if (cb + (PM_THREADS / 64) * 32 < D) {
+      set_rows(cb + (PM_THREADS / 64) * 32);
+      if (ksteps > 0) load_step(0, 0);
     }
     // ---- combine: the lane holds channels c .. c + 7 (rows 4 kg + r of tiles t = 0, 1) of cell 16 nf + li
     const int c = cb + 8 * kg;

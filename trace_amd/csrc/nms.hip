@@ -241,13 +241,17 @@ __global__ __launch_bounds__(1024) void nms_reduce_kernel(const uint64_t* __rest
   setA.base = setB.base = 0;
   // helper step: OR in what this set loaded two iterations ago, then load the kept rows of block `blk`
   auto helper_step = [&](NmsPushSet<WPL>& st, int blk) {
+    // the wave's (up to five) kept rows are OR-ed in registers first: one LDS atomic per word instead of one per row
 #pragma unroll
-    for (int j = 0; j < NMS_ROWS_PER_HELPER; ++j)
+    for (int k = 0; k < WPL; ++k) {
+      uint64_t m = 0ULL;
 #pragma unroll
-      for (int k = 0; k < WPL; ++k) {
-        if (st.v[j][k]) atomicOr(&remv[st.base + k * 64 + lane], (unsigned long long)st.v[j][k]);
+      for (int j = 0; j < NMS_ROWS_PER_HELPER; ++j) {
+        m |= st.v[j][k];
         st.v[j][k] = 0ULL;
       }
+      if (m) atomicOr(&remv[st.base + k * 64 + lane], (unsigned long long)m);
+    }
     if (blk < 0) return;
     const int cnt = keptcnt[blk & 1];
     st.base = blk + 1 + NMS_CARRY;
