@@ -212,11 +212,12 @@ def test_step_graph_is_bit_stable_at_bench_size(setup):
                 got = snap(run(case))
                 for ci, (og, ow) in enumerate(zip(got, ref)):
                     _same(og, ow, keys, "side stream, repeat %d, clip %d" % (it, ci))
-        # software-pipelined steps (with and without the second stream): results arrive one call later
-        for side in (False, True):
+        # software-pipelined steps (with and without the second stream; cut behind the backbone or - bench.py's default -
+        # behind layer3, so that the late stages run beside the next step's early ones): results arrive one call later
+        for side, split in ((False, None), (True, None), (True, 2), (False, 1)):
             m.drop_graphs()
-            m.side_stream, m.overlap_steps = side, True
-            seq = [a, b] * 8
+            m.side_stream, m.overlap_steps, m.split_stage = side, True, split
+            seq = [a, b] * (8 if split is None else 5)
             got = []
             for case in seq:
                 outs = run(case)
@@ -226,9 +227,10 @@ def test_step_graph_is_bit_stable_at_bench_size(setup):
             assert len(got) == len(seq)
             for i, g in enumerate(got):
                 for ci, (og, ow) in enumerate(zip(g, ra if i % 2 == 0 else rb)):
-                    _same(og, ow, keys, "overlapped (side %s), step %d, clip %d" % (side, i, ci))
+                    _same(og, ow, keys, "overlapped (side %s, split %s), step %d, clip %d" % (side, split, i, ci))
     finally:
         m.flush_steps()
+        m.split_stage = None
         m.overlap_steps = False
         m.graph_step = False
         m.side_stream = False
@@ -319,10 +321,10 @@ def test_overlapped_steps_equal_step_graph(setup):
         m.side_stream, m.graph_step, m.overlap_steps = False, True, False
         m.drop_graphs()
         want = [snap(run(case)) for case in seq]
-        for side in (False, True):
+        for side, split in ((False, None), (True, None), (False, 2), (True, 2), (True, 0)):
             m.side_stream, m.graph_step = side, True
             m.drop_graphs()
-            m.overlap_steps = True
+            m.overlap_steps, m.split_stage = True, split
             got = []
             for case in seq:
                 outs = run(case)
@@ -333,9 +335,10 @@ def test_overlapped_steps_equal_step_graph(setup):
             assert len(got) == len(want)
             for i, (g, w) in enumerate(zip(got, want)):
                 for og, ow in zip(g, w):
-                    _same(og, ow, keys, "overlapped, side_stream %s, step %d" % (side, i))
+                    _same(og, ow, keys, "overlapped, side_stream %s, split %s, step %d" % (side, split, i))
     finally:
         m.flush_steps()
+        m.split_stage = None
         m.overlap_steps = False
         m.graph_step = False
         m.side_stream = False

@@ -209,6 +209,11 @@ class Generalized_RCNN(PackedLinears):
         # the next call or sync_steps()).  Measured on MI355X: no gain over depth 1 (2634 vs 2653 clips/s), so 1 is the default
         self.pipeline = 1
         self.side_fork_stage = 1      # fork after layer2 (0-based residual stage index; -1 = after the stem)
+        # overlap_steps: where a step is cut into its two pipelined halves.  None: behind the backbone (the tail of step
+        # n-1 runs beside the whole backbone of step n).  i: behind residual stage i - the first half is stem .. stage i
+        # plus part A, the second half the remaining stages plus the tail, so that the HBM-bound early stages of step n
+        # run beside the MFMA-bound late stages of step n-1 (tools/overlap_probe.py: 1834 -> 1581 us for the backbone)
+        self.split_stage = None
         # pair attention + spatio_inferA/B as one kernel on [V | W_A V | W_B V] maps (see ops.pair_infer); off:
         # the reference's order of operations (pool, attend, then the two 1x1 convs as a GEMM)
         self.fuse_pair_infer = True
@@ -538,7 +543,7 @@ class Generalized_RCNN(PackedLinears):
         key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
                self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage,
-               self.pair_mfma)
+               self.pair_mfma, self.split_stage)
         depth = max(1, int(self.pipeline))
         ents = self._step_graphs.get(key)
         if ents is None:
@@ -629,7 +634,7 @@ class Generalized_RCNN(PackedLinears):
         key = (tuple(all_frames.shape), all_frames.dtype, tuple(blob_conv.shape), blob_conv.dtype, tuple(feat_map.shape),
                feat_map.dtype, prep["sig"], topk, prd_k, dev.index, _PACK_EPOCH[0], self._pk_epoch,
                self.side_stream, self.split_pair_pool, self.fuse_pair_infer, self.share_swapped_pairs, self.side_fork_stage,
-               self.pair_mfma)
+               self.pair_mfma, self.split_stage)
         flushed = None
         if self._ov_pending is not None and self._ov_pending["key"] != key:
             flushed = self.flush_steps()          # another step signature: no graph holds that pair of steps
@@ -1089,9 +1094,17 @@ class Generalized_RCNN(PackedLinears):
                           so_bias=so_bias, so_part=so_part, n_rel=n_rel)
 
         # ---- I3D backbone (:978-981)
+        split = self.split_stage if phase in ("a", "b") else None
         if phase == "b":
             pa = dict(hand)
             tmaps = hand["tmaps"]
+            if split is not None:        # `tmaps` is the activation behind stage `split`: the late stages run here
+                tmaps = self.Prd_RCNN.forward_ndhwc(tmaps, start_at=split + 1)
+        elif split is not None:
+            hook = (min(self.side_fork_stage, split), part_a) if self.side_stream else None
+            if hook is None:
+                part_a()
+            tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True, stage_hook=hook, stop_after=split)
         else:
             hook = None
             if self.side_stream and not graph_backbone:
@@ -1107,16 +1120,16 @@ class Generalized_RCNN(PackedLinears):
                                                            pa["vab"], pa["bias_ab"])
         sbj_lab_all, obj_lab_all, sbj_sc_all, obj_sc_all = pa["sbj_lab_all"], pa["obj_lab_all"], pa["sbj_sc_all"], pa["obj_sc_all"]
         so_bias, so_part, n_rel = pa["so_bias"], pa["so_part"], pa["n_rel"]
-        Tn = tmaps.shape[1]
-        if Tn != prep["Tn"]:
-            raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))
-        tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
         if self.side_stream and phase != "b":
             main.wait_stream(side)
         if phase == "a":
             out = dict(pa)
             out["tmaps"] = tmaps
             return out
+        Tn = tmaps.shape[1]
+        if Tn != prep["Tn"]:
+            raise RuntimeError("backbone produced %d frames, host lists were built for %d" % (Tn, prep["Tn"]))
+        tm_flat = tmaps.view(B * Tn, tmaps.shape[2], tmaps.shape[3], tmaps.shape[4])
 
         # ---- cluster_tree3d: temporal object features (:158-201)
         def temporal_branch(rois_d, cur_feat, cur_feat_bf, fc, q_s_l, q_o_l, val, tag):

@@ -493,21 +493,25 @@ class ResNet3d(nn.Module):
                             alg_k=kt * kh * kw * C)
         return ops.maxpool3d(y, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
-    def forward_ndhwc(self, x, in_ntchw=False, stage_hook=None):
+    def forward_ndhwc(self, x, in_ntchw=False, stage_hook=None, stop_after=None, start_at=None):
         """x f32 (N,C,T,H,W) (or (N,T,C,H,W) with in_ntchw), or uint8 decoded frames (N,T,H,W,C) from which
         `pixel_means` is subtracted on the fly -> channels-last bf16 (N,T',H',W',feat_dim).
         stage_hook: optional (stage_index, callable): the callable runs right after residual stage `stage_index`
         (0-based; -1 = after the stem) has been launched - the relation head forks its weight-streaming branch
-        onto a second stream there."""
+        onto a second stream there.  stop_after = i: return the activation behind residual stage i; start_at = i: `x` is
+        such an activation and the pass resumes with stage i (the two halves of a software-pipelined step)."""
         if self.training:
             raise NotImplementedError("trace_amd.ResNet3d implements the inference path; call .eval()")
         with torch.no_grad():
-            x = self._run_stem(x, in_ntchw)
-            if ops.PROBE is not None:
-                ops.PROBE.append(("stem", x))
-            if stage_hook is not None and stage_hook[0] == -1:
-                stage_hook[1]()
+            if start_at is None:
+                x = self._run_stem(x, in_ntchw)
+                if ops.PROBE is not None:
+                    ops.PROBE.append(("stem", x))
+                if stage_hook is not None and stage_hook[0] == -1:
+                    stage_hook[1]()
             for i, name in enumerate(self.res_layers[:self.num_stages]):
+                if start_at is not None and i < start_at:
+                    continue
                 blocks = list(getattr(self, name))
                 for bi, blk in enumerate(blocks):
                     # pool2 (resnet3d.py:798-799) rides in the epilogue of layer1's last conv3
@@ -517,6 +521,8 @@ class ResNet3d(nn.Module):
                         ops.PROBE.append(("%s.%d" % (name, bi), x))
                 if stage_hook is not None and stage_hook[0] == i:
                     stage_hook[1]()
+                if stop_after is not None and i == stop_after:
+                    break
         return x
 
     def forward_train(self, x, in_ntchw=False):
