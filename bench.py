@@ -45,8 +45,8 @@ I3D_GFLOP_PER_CLIP = 108.1  # reference algorithm @ 32 x 224^2
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU per step")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--objects", type=int, default=20)
@@ -58,6 +58,9 @@ def parse():
                     help="with --overlap: cut the pipelined step behind this residual stage (0-based; 2 = layer3) instead of "
                          "behind the backbone (-1): stem .. layer3 + part A of step n then run beside layer4 + the head of "
                          "step n-1 (measured 2.46 -> 2.34 ms per step; same bits)")
+    ap.add_argument("--split-block", type=int, default=3,
+                    help="> 0: cut behind the first k blocks of stage --split-stage instead of behind the whole stage (0); "
+                         "measured behind layer3's blocks 1 / 2 / 3 / 4 / 5 / 6: 2.39 / 2.28 / 2.25-2.27 / 2.31 / 2.31 / 2.34 ms")
     ap.add_argument("--side-fork", type=int, default=None,
                     help="residual stage behind which part A forks onto the second stream (model.side_fork_stage; -1 = stem)")
     ap.add_argument("--side-stream", type=int, default=1,
@@ -203,6 +206,8 @@ def main():
     # results of step n-1; every timed region below ends with flush_steps(), so K calls = K complete steps
     model.overlap_steps = bool(args.overlap) and args.pipeline == 1
     model.split_stage = args.split_stage if args.split_stage >= 0 else None
+    if model.split_stage is not None and args.split_block > 0:
+        model.split_stage = (args.split_stage, args.split_block)
     if args.side_fork is not None:
         model.side_fork_stage = args.side_fork
     calib = torch.randn((1, 3, 16, 112, 112), generator=torch.Generator().manual_seed(1)) * 50
@@ -358,7 +363,7 @@ def main():
         "roofline_nms": kern and {"rpn": kern["nms_rpn"], "per_class": kern["nms_per_class"]},
         "i3d_algorithmic_tflops": value * I3D_GFLOP_PER_CLIP / 1e3,
         "prd_k": args.prd_k, "overlap_steps": bool(args.overlap) and args.pipeline == 1, "side_stream": bool(args.side_stream),
-        "split_stage": (args.split_stage if args.split_stage >= 0 else None) if (bool(args.overlap) and args.pipeline == 1) else None,
+        "split_stage": ((args.split_stage, args.split_block) if args.split_block > 0 else args.split_stage) if (bool(args.overlap) and args.pipeline == 1 and args.split_stage >= 0) else None,
         "other_configs": second,
     }
     print(json.dumps(out))

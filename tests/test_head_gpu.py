@@ -213,8 +213,8 @@ def test_step_graph_is_bit_stable_at_bench_size(setup):
                 for ci, (og, ow) in enumerate(zip(got, ref)):
                     _same(og, ow, keys, "side stream, repeat %d, clip %d" % (it, ci))
         # software-pipelined steps (with and without the second stream; cut behind the backbone or - bench.py's default -
-        # behind layer3, so that the late stages run beside the next step's early ones): results arrive one call later
-        for side, split in ((False, None), (True, None), (True, 2), (False, 1)):
+        # behind the third block of layer3, so that the late blocks run beside the next step's early ones): results arrive one call later
+        for side, split in ((False, None), (True, None), (True, (2, 3)), (False, 1)):
             m.drop_graphs()
             m.side_stream, m.overlap_steps, m.split_stage = side, True, split
             seq = [a, b] * (8 if split is None else 5)
@@ -321,7 +321,7 @@ def test_overlapped_steps_equal_step_graph(setup):
         m.side_stream, m.graph_step, m.overlap_steps = False, True, False
         m.drop_graphs()
         want = [snap(run(case)) for case in seq]
-        for side, split in ((False, None), (True, None), (False, 2), (True, 2), (True, 0)):
+        for side, split in ((False, None), (True, None), (False, 2), (True, (2, 3)), (True, (3, 1)), (True, 0)):
             m.side_stream, m.graph_step = side, True
             m.drop_graphs()
             m.overlap_steps, m.split_stage = True, split

@@ -210,7 +210,8 @@ class Generalized_RCNN(PackedLinears):
         self.pipeline = 1
         self.side_fork_stage = 1      # fork after layer2 (0-based residual stage index; -1 = after the stem)
         # overlap_steps: where a step is cut into its two pipelined halves.  None: behind the backbone (the tail of step
-        # n-1 runs beside the whole backbone of step n).  i: behind residual stage i - the first half is stem .. stage i
+        # n-1 runs beside the whole backbone of step n).  i (or (i, k): behind the first k blocks of stage i): behind
+        # residual stage i - the first half is stem .. stage i
         # plus part A, the second half the remaining stages plus the tail, so that the HBM-bound early stages of step n
         # run beside the MFMA-bound late stages of step n-1 (tools/overlap_probe.py: 1834 -> 1581 us for the backbone)
         self.split_stage = None
@@ -1099,9 +1100,11 @@ class Generalized_RCNN(PackedLinears):
             pa = dict(hand)
             tmaps = hand["tmaps"]
             if split is not None:        # `tmaps` is the activation behind stage `split`: the late stages run here
-                tmaps = self.Prd_RCNN.forward_ndhwc(tmaps, start_at=split + 1)
+                tmaps = self.Prd_RCNN.forward_ndhwc(tmaps, start_at=split)
         elif split is not None:
-            hook = (min(self.side_fork_stage, split), part_a) if self.side_stream else None
+            # part A forks behind `side_fork_stage` if the first half runs that far, else behind its last whole stage
+            whole = split if isinstance(split, int) else split[0] - 1
+            hook = (min(self.side_fork_stage, whole), part_a) if self.side_stream else None
             if hook is None:
                 part_a()
             tmaps = self.Prd_RCNN.forward_ndhwc(all_frames, in_ntchw=True, stage_hook=hook, stop_after=split)

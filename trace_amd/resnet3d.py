@@ -498,10 +498,22 @@ class ResNet3d(nn.Module):
         `pixel_means` is subtracted on the fly -> channels-last bf16 (N,T',H',W',feat_dim).
         stage_hook: optional (stage_index, callable): the callable runs right after residual stage `stage_index`
         (0-based; -1 = after the stem) has been launched - the relation head forks its weight-streaming branch
-        onto a second stream there.  stop_after = i: return the activation behind residual stage i; start_at = i: `x` is
-        such an activation and the pass resumes with stage i (the two halves of a software-pipelined step)."""
+        onto a second stream there.  stop_after = i or (i, k): return the activation behind residual stage i (behind
+        its first k blocks); start_at = the same value: `x` is such an activation and the pass resumes right behind that
+        point (the two halves of a software-pipelined step)."""
         if self.training:
             raise NotImplementedError("trace_amd.ResNet3d implements the inference path; call .eval()")
+
+        def cut(v):   # -> (stage, blocks of it on the near side)
+            if v is None:
+                return None
+            i, k = (v, None) if isinstance(v, int) else v
+            n = len(getattr(self, self.res_layers[i]))
+            k = n if k is None else k
+            if not 0 < k <= n:
+                raise ValueError("cut (%d, %d): stage %d has %d blocks" % (i, k, i, n))
+            return i, k
+        stop, start = cut(stop_after), cut(start_at)
         with torch.no_grad():
             if start_at is None:
                 x = self._run_stem(x, in_ntchw)
@@ -510,19 +522,23 @@ class ResNet3d(nn.Module):
                 if stage_hook is not None and stage_hook[0] == -1:
                     stage_hook[1]()
             for i, name in enumerate(self.res_layers[:self.num_stages]):
-                if start_at is not None and i < start_at:
+                if start is not None and i < start[0]:
                     continue
                 blocks = list(getattr(self, name))
                 for bi, blk in enumerate(blocks):
+                    if start is not None and i == start[0] and bi < start[1]:
+                        continue
                     # pool2 (resnet3d.py:798-799) rides in the epilogue of layer1's last conv3
                     blk.res_f32 = i in self.res_f32_stages
                     x = blk.run(x, pool_t2=(i == 0 and self.with_pool2 and bi == len(blocks) - 1))
                     if ops.PROBE is not None:
                         ops.PROBE.append(("%s.%d" % (name, bi), x))
+                    if stop is not None and (i, bi + 1) == stop:
+                        if bi + 1 == len(blocks) and stage_hook is not None and stage_hook[0] == i:
+                            stage_hook[1]()
+                        return x
                 if stage_hook is not None and stage_hook[0] == i:
                     stage_hook[1]()
-                if stop_after is not None and i == stop_after:
-                    break
         return x
 
     def forward_train(self, x, in_ntchw=False):
