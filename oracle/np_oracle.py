@@ -2,9 +2,10 @@
 
 Pinned by execution: tests/golden/py_box_glue.npz, py_tree.npz and py_relpn.npz hold outputs of the
 reference's own functions (run on the CPU of the build container by tools/make_goldens_py.py) and
-tests/test_oracle_goldens_py.py checks every function here against them bit for bit.  Not reachable
-that way (Cython sources do not build here): bbox_overlaps / bbox_pair_overlaps / the overlap filter
-and box_results_with_nms_and_limit, which follow the cited lines only.
+tests/test_oracle_goldens_py.py checks every function here against them bit for bit.  bbox_overlaps /
+bbox_pair_overlaps (oracle/trace_oracle.c) are pinned since round 3 by the reference's own Cython modules compiled
+here (tests/golden/cy_overlaps.npz, tests/test_oracle_goldens_r3.py); box_results_with_nms_and_limit is pinned by
+tests/golden/py_det_branch.npz.
 """
 import math
 

@@ -229,15 +229,19 @@ int oracle_nms(const float* boxes, const float* scores, int N, float thresh, int
 void oracle_bbox_overlaps(const float* boxes, int N, const float* query, int K, float* out) {
   for (int k = 0; k < K; k++) {
     const float* q = query + k * 4;
-    float box_area = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+    /* Cython turns the integer literal beside a float32 operand into the C double 1.0: differences are float32, "+ 1",
+       the products and the sum of `ua` run in double and are rounded to float32 on assignment (pinned by
+       tests/golden/cy_overlaps.npz, the compiled .pyx's own outputs; an all-float32 restatement is 1 ulp off in 1-5 %
+       of the entries) */
+    float box_area = (float)(((double)(q[2] - q[0]) + 1.0) * ((double)(q[3] - q[1]) + 1.0));
     for (int n = 0; n < N; n++) {
       const float* b = boxes + n * 4;
       float o = 0.f;
-      float iw = fminf(b[2], q[2]) - fmaxf(b[0], q[0]) + 1;
+      float iw = (float)((double)(fminf(b[2], q[2]) - fmaxf(b[0], q[0])) + 1.0);
       if (iw > 0) {
-        float ih = fminf(b[3], q[3]) - fmaxf(b[1], q[1]) + 1;
+        float ih = (float)((double)(fminf(b[3], q[3]) - fmaxf(b[1], q[1])) + 1.0);
         if (ih > 0) {
-          float ua = (b[2] - b[0] + 1) * (b[3] - b[1] + 1) + box_area - iw * ih;
+          float ua = (float)(((double)(b[2] - b[0]) + 1.0) * ((double)(b[3] - b[1]) + 1.0) + (double)box_area - (double)(iw * ih));
           o = iw * ih / ua;
         }
       }
@@ -250,13 +254,13 @@ void oracle_bbox_overlaps(const float* boxes, int N, const float* query, int K, 
 void oracle_bbox_pair_overlaps(const float* b1, const float* b2, int N, float* out) {
   for (int n = 0; n < N; n++) {
     const float* a = b1 + n * 4; const float* q = b2 + n * 4;
-    float box_area = (q[2] - q[0] + 1) * (q[3] - q[1] + 1);
+    float box_area = (float)(((double)(q[2] - q[0]) + 1.0) * ((double)(q[3] - q[1]) + 1.0));   /* as above */
     float o = 0.f;
-    float iw = fminf(a[2], q[2]) - fmaxf(a[0], q[0]) + 1;
+    float iw = (float)((double)(fminf(a[2], q[2]) - fmaxf(a[0], q[0])) + 1.0);
     if (iw > 0) {
-      float ih = fminf(a[3], q[3]) - fmaxf(a[1], q[1]) + 1;
+      float ih = (float)((double)(fminf(a[3], q[3]) - fmaxf(a[1], q[1])) + 1.0);
       if (ih > 0) {
-        float ua = (a[2] - a[0] + 1) * (a[3] - a[1] + 1) + box_area - iw * ih;
+        float ua = (float)(((double)(a[2] - a[0]) + 1.0) * ((double)(a[3] - a[1]) + 1.0) + (double)box_area - (double)(iw * ih));
         o = iw * ih / ua;
       }
     }

@@ -202,3 +202,26 @@ def test_box_helpers_bitexact():
         rs, ro, rrel = np_oracle.relpn_pairs(r)
         assert np.array_equal(s.cpu().numpy(), rs) and np.array_equal(o.cpu().numpy(), ro)
         assert np.array_equal(rel.cpu().numpy(), rrel.astype(np.float32))
+
+
+@pytest.mark.parametrize("case", ["rand", "dense", "touch", "big"])
+def test_bbox_overlaps_vs_reference_cython_golden(case):
+    """trace_bbox_overlaps against the outputs of the reference's own cython_bbox.bbox_overlaps (compiled from its .pyx,
+    tests/golden/cy_overlaps.npz): bit for bit."""
+    import os
+    from trace_amd import boxes as tb
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cy_overlaps.npz"))
+    a, b = G["ov_%s_a" % case], G["ov_%s_b" % case]
+    got = tb.bbox_overlaps(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, G["ov_%s_out" % case])
+
+
+@pytest.mark.parametrize("case", ["rand", "dense", "touch"])
+def test_bbox_pair_overlaps_vs_reference_cython_golden(case):
+    """trace_bbox_pair_overlaps against cython_bbox_rel.bbox_pair_overlaps' own outputs: bit for bit."""
+    import os
+    from trace_amd import boxes as tb
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cy_overlaps.npz"))
+    a, b = G["po_%s_a" % case], G["po_%s_b" % case]
+    got = tb.bbox_pair_overlaps(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    assert np.array_equal(got, G["po_%s_out" % case])

@@ -30,6 +30,21 @@ __global__ __launch_bounds__(256) void fpn_levels_kernel(const float* __restrict
   levels[i] = lvl;
 }
 
+// IoU with "+ 1" extents exactly as the reference's Cython modules compute it: Cython emits the integer literal beside a
+// float32 operand as the C double 1.0, so the coordinate differences are float32 while "+ 1", the area products and the
+// sum of the union run in double and are rounded to float32 when they are assigned (box_area, iw, ih, ua are float32
+// variables); iw * ih and the final division are float32.  Pinned bit for bit by tests/golden/cy_overlaps.npz (outputs
+// of the compiled .pyx files); an all-float32 form is 1 ulp off in 1-5 % of the entries.
+__device__ __forceinline__ float iou_plus1_cython(const float* b, const float* q) {
+  const float box_area = (float)(((double)(q[2] - q[0]) + 1.0) * ((double)(q[3] - q[1]) + 1.0));
+  const float iw = (float)((double)(fminf(b[2], q[2]) - fmaxf(b[0], q[0])) + 1.0);
+  if (!(iw > 0.f)) return 0.f;
+  const float ih = (float)((double)(fminf(b[3], q[3]) - fmaxf(b[1], q[1])) + 1.0);
+  if (!(ih > 0.f)) return 0.f;
+  const float ua = (float)(((double)(b[2] - b[0]) + 1.0) * ((double)(b[3] - b[1]) + 1.0) + (double)box_area - (double)(iw * ih));
+  return iw * ih / ua;
+}
+
 __global__ __launch_bounds__(256) void bbox_overlaps_kernel(const float* __restrict__ boxes, int N,
                                                             const float* __restrict__ query, int K,
                                                             float* __restrict__ out) {
@@ -38,18 +53,8 @@ __global__ __launch_bounds__(256) void bbox_overlaps_kernel(const float* __restr
   int n = (int)(idx / K), k = (int)(idx % K);
   const float* q = query + k * 4;
   const float* b = boxes + n * 4;
-  // cython_bbox.pyx:52-72
-  float box_area = (q[2] - q[0] + 1.0f) * (q[3] - q[1] + 1.0f);
-  float o = 0.f;
-  float iw = fminf(b[2], q[2]) - fmaxf(b[0], q[0]) + 1.0f;
-  if (iw > 0.f) {
-    float ih = fminf(b[3], q[3]) - fmaxf(b[1], q[1]) + 1.0f;
-    if (ih > 0.f) {
-      float ua = (b[2] - b[0] + 1.0f) * (b[3] - b[1] + 1.0f) + box_area - iw * ih;
-      o = iw * ih / ua;
-    }
-  }
-  out[idx] = o;
+  // cython_bbox.pyx:52-72 as the compiled module evaluates it (iou_plus1_cython below)
+  out[idx] = iou_plus1_cython(b, q);
 }
 
 __global__ __launch_bounds__(256) void bbox_pair_overlaps_kernel(const float* __restrict__ b1,
@@ -59,18 +64,8 @@ __global__ __launch_bounds__(256) void bbox_pair_overlaps_kernel(const float* __
   if (n >= N) return;
   const float* a = b1 + n * 4;
   const float* q = b2 + n * 4;
-  // cython_bbox_rel.pyx:57-76
-  float box_area = (q[2] - q[0] + 1.0f) * (q[3] - q[1] + 1.0f);
-  float o = 0.f;
-  float iw = fminf(a[2], q[2]) - fmaxf(a[0], q[0]) + 1.0f;
-  if (iw > 0.f) {
-    float ih = fminf(a[3], q[3]) - fmaxf(a[1], q[1]) + 1.0f;
-    if (ih > 0.f) {
-      float ua = (a[2] - a[0] + 1.0f) * (a[3] - a[1] + 1.0f) + box_area - iw * ih;
-      o = iw * ih / ua;
-    }
-  }
-  out[n] = o;
+  // cython_bbox_rel.pyx:57-76, same expression
+  out[n] = iou_plus1_cython(a, q);
 }
 
 // All ordered pairs (s,o), s != o, in the reference's repeat/tile order

@@ -26,13 +26,19 @@ def bbox_overlaps(boxes, query_boxes):
     out = np.zeros((N, K), np.float32)
     if N == 0 or K == 0:
         return out
-    qa = (query_boxes[:, 2] - query_boxes[:, 0] + 1) * (query_boxes[:, 3] - query_boxes[:, 1] + 1)
-    ba = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
-    iw = np.minimum(boxes[:, None, 2], query_boxes[None, :, 2]) - np.maximum(boxes[:, None, 0], query_boxes[None, :, 0]) + 1
-    ih = np.minimum(boxes[:, None, 3], query_boxes[None, :, 3]) - np.maximum(boxes[:, None, 1], query_boxes[None, :, 1]) + 1
+    # The compiled Cython evaluates "+ 1" and the area products / the union's sum in double (the literal becomes the C
+    # double 1.0) and rounds to float32 when box_area, iw, ih, ua are assigned; differences, iw * ih and the division are
+    # float32.  Bit for bit the module's own outputs (tests/golden/cy_overlaps.npz).
+    f8 = np.float64
+    d = lambda hi, lo: (hi - lo).astype(f8) + 1.0                                   # float32 difference, double "+ 1"
+    qa = (d(query_boxes[:, 2], query_boxes[:, 0]) * d(query_boxes[:, 3], query_boxes[:, 1])).astype(np.float32)
+    ba = d(boxes[:, 2], boxes[:, 0]) * d(boxes[:, 3], boxes[:, 1])                  # stays double inside `ua`
+    iw = d(np.minimum(boxes[:, None, 2], query_boxes[None, :, 2]), np.maximum(boxes[:, None, 0], query_boxes[None, :, 0])).astype(np.float32)
+    ih = d(np.minimum(boxes[:, None, 3], query_boxes[None, :, 3]), np.maximum(boxes[:, None, 1], query_boxes[None, :, 1])).astype(np.float32)
     ok = (iw > 0) & (ih > 0)
-    ua = ba[:, None] + qa[None, :] - iw * ih
-    out[ok] = (iw * ih)[ok] / ua[ok]
+    inter = iw * ih                                                                 # float32
+    ua = (ba[:, None] + qa[None, :].astype(f8) - inter.astype(f8)).astype(np.float32)
+    out[ok] = inter[ok] / ua[ok]
     return out
 
 
