@@ -37,6 +37,28 @@ def test_nms_grouped_equals_per_group_nms(N, groups):
     assert np.array_equal(keep.cpu().numpy(), ref)
 
 
+def test_nms_grouped_ragged_groups_and_sparse_ids():
+    """One class with 2500 boxes (a 40-block chain), 60 single-box classes, classes of 63 / 64 / 65 boxes that start and end
+    on and off 64-box block boundaries, sparse class ids up to 2^18 - 2: same keeps as per-class NMS."""
+    from trace_amd import boxes as B
+    rng = np.random.default_rng(77)
+    sizes = [2500, 63, 64, 65, 1, 1, 129] + [1] * 58 + [300]
+    ids = rng.choice(np.arange(1, 2 ** 18 - 1), size=len(sizes), replace=False).astype(np.int32)
+    ids[0], ids[-1] = 2 ** 18 - 2, 0
+    gr = np.concatenate([np.full(n, i, np.int32) for n, i in zip(sizes, ids)])
+    perm = rng.permutation(gr.shape[0])
+    gr = gr[perm]
+    N = gr.shape[0]
+    bx = synth_boxes(rng, N, 1.5)
+    sc = distinct_scores(rng, N)
+    keep = B.nms_grouped(torch.from_numpy(bx).to(DEV), torch.from_numpy(sc).to(DEV), torch.from_numpy(gr).to(DEV), 0.5)
+    ref = []
+    for g in ids:
+        idx = np.where(gr == g)[0]
+        ref.append(idx[c_oracle.nms(np.ascontiguousarray(bx[idx]), np.ascontiguousarray(sc[idx]), 0.5, 0)])
+    assert np.array_equal(keep.cpu().numpy(), np.sort(np.concatenate(ref)))
+
+
 def test_nms_large_single_group_vs_oracle():
     from trace_amd import _C
     rng = np.random.default_rng(3)

@@ -23,7 +23,7 @@ def test_temporal_attention():
 
 @pytest.mark.parametrize("lds_resident", [False, True, "narrow"])
 @pytest.mark.parametrize("n,G,F_,Hd", [(1, 1, 64, 64), (7, 4, 64, 64), (20, 4, 64, 64), (33, 2, 256, 256), (50, 4, 256, 256),
-                                       (19, 1, 128, 512)])
+                                       (19, 1, 128, 512), (1, 2, 256, 256), (9, 1, 1024, 1024)])
 def test_tree_gru_vs_dense_reference(n, G, F_, Hd, lds_resident):
     """tree-GRU on CSR arrays (HIP; the level-walking kernel, the LDS-resident one selected by a tree-size bound, and -
     for matrices beyond LDS, 256 x 256 of the Action Genome head - the batched products streamed from L2; "narrow" =
