@@ -1030,6 +1030,7 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) aoffs[odd][s2] = ST_PATCH + lds_off_a(wm * 32 + perm_row(odd, fr), s2 * 4 + fq);
   const int lane_b = wn * (16 * ST_ROWB) + (fr + fq) * 16;
+  bf16x8 rf[2][11];   // patch-row fragments of the current frame tap, by row parity (see the K loop)
 
 #pragma unroll
   for (int ks = 0; ks < ST_KSTEPS; ++ks) {
@@ -1057,11 +1058,18 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
       const int kt_i = tap / ST_KH, kh_i = tap % ST_KH;
       const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + abase + aoffs[0][s2]);
       const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + abase + aoffs[1][s2]);
+      // output row j under tap kh reads patch row 2 j + kh = 2 (j + kh / 2) + (kh & 1): the eight fragments of tap kh
+      // are those of tap kh - 2 moved up one row.  Each patch row of a frame is therefore read ONCE (21 reads per kt
+      // instead of 56) and kept in registers while the taps slide over it (the loop is fully unrolled: rf[][] are
+      // registers, dead entries are dropped); the K loop was LDS-read bound at 10 fragment reads per 16 MFMAs
+      const int par = kh_i & 1, sl = kh_i >> 1;
+#pragma unroll
+      for (int u = (sl == 0 ? 0 : sl + 7); u < sl + 8; ++u)
+        rf[par][u] = *reinterpret_cast<const bf16x8*>(smem + lane_b + (kt_i * ST_PR + 2 * u + par) * ST_ROWB);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + lane_b + (kt_i * ST_PR + 2 * j + kh_i) * ST_ROWB);
-        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][j], 0, 0, 0);
-        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][j], 0, 0, 0);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, rf[par][j + sl], acc[0][j], 0, 0, 0);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, rf[par][j + sl], acc[1][j], 0, 0, 0);
       }
     }
   }
