@@ -1,0 +1,129 @@
+// Probe (diagnostic, not product code): what read rate does HBM give a weight-streaming kernel on this GPU, and does
+// the ORDER in which the workgroups walk the matrix matter?
+//
+//   hipcc --offload-arch=gfx950 -O3 -o tools/stream_probe tools/stream_probe.hip && tools/stream_probe
+//
+// 616 MB (fc1's weight matrix: 24 cout tiles x 1568 K-steps x 16 KiB blocks) is read once by 504 workgroups (24 tiles x
+// 21 K-slices of 75 K-steps, as the FC launches them, two per CU on 252 CUs) with 16-byte loads, DEPTH blocks in flight
+// per workgroup.  Layouts of the blocks in memory:
+//   tile-major   block (tile, ks) at tile * 1568 + ks        (what ops.tile_weights produces)
+//   step-major   block (tile, ks) at ks * 24 + tile          (the 24 tiles of a K-step adjacent)
+//   linear       workgroup g reads blocks g, g + 504, ...    (upper bound: perfectly interleaved streams)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+constexpr int TILES = 24, KSTEPS = 1568, SLICES = 21, PER = 75;   // 21 * 75 = 1575 >= 1568
+constexpr int BLOCK = 16384;
+
+template <int MODE, int DEPTH>
+__global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ w, uint4* __restrict__ sink) {
+  const int g = blockIdx.x;
+  const int tile = g % TILES, slice = g / TILES;
+  const int ks0 = slice * PER, ks1 = min(ks0 + PER, KSTEPS);
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (int ks = ks0; ks < ks1; ks += DEPTH) {
+    uint4 v[DEPTH][4];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int k = min(ks + d, ks1 - 1);
+      long long blk;
+      if (MODE == 0) blk = (long long)tile * KSTEPS + k;
+      else if (MODE == 1) blk = (long long)k * TILES + tile;
+      else blk = (long long)(k - ks0) * (TILES * SLICES) + g;
+      if (MODE == 2 && blk >= (long long)TILES * KSTEPS) blk = g;
+      const uint4* p = w + blk * (BLOCK / 16) + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[d][i] = p[i * 256];
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc.x ^= v[d][i].x; acc.y ^= v[d][i].y; acc.z ^= v[d][i].z; acc.w ^= v[d][i].w;
+      }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[g * 256 + threadIdx.x] = acc;
+}
+
+__global__ void fill_kernel(uint4* p, long long n, uint32_t seed) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += st) {
+    const uint32_t j = (uint32_t)i * 2654435761u + seed;
+    p[i] = make_uint4(j, j ^ 0x9e3779b9u, ~j, j * 31u);
+  }
+}
+
+__global__ void read_kernel(const uint4* p, long long n, uint4* sink) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long st = (long long)gridDim.x * blockDim.x;
+  uint4 a = make_uint4(0, 0, 0, 0);
+  for (; i < n; i += st) {
+    const uint4 v = p[i];
+    a.x ^= v.x; a.y ^= v.y; a.z ^= v.z; a.w ^= v.w;
+  }
+  if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) sink[threadIdx.x] = a;
+}
+
+static bool g_clean_flush = false;   // evict by READING the flush buffer: the caches then hold clean lines only
+
+template <int MODE, int DEPTH>
+static void run(const char* name, const uint4* w, uint4* sink, uint4* flush, long long flush_n) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  float best = 1e30f, sum = 0.f;
+  const int reps = 6;
+  for (int r = 0; r < reps; ++r) {
+    if (g_clean_flush) hipLaunchKernelGGL(read_kernel, dim3(4096), dim3(256), 0, 0, flush, flush_n, sink);
+    else hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, flush, flush_n, (uint32_t)r);   // evict L2 / MALL
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((stream_kernel<MODE, DEPTH>), dim3(TILES * SLICES), dim3(256), 0, 0, w, sink);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r) { best = ms < best ? ms : best; sum += ms; }
+  }
+  const double bytes = (double)TILES * KSTEPS * BLOCK;
+  printf("%-11s depth %d  best %7.1f us  mean %7.1f us  %5.2f TB/s\n", name, DEPTH, best * 1e3, sum / (reps - 1) * 1e3,
+         bytes / (best * 1e-3) * 1e-12);
+}
+
+int main() {
+  const long long n = (long long)TILES * KSTEPS * (BLOCK / 16);
+  uint4 *w, *sink, *flush;
+  const long long flush_n = (1LL << 30) / 16;
+  CHECK(hipMalloc(&w, n * 16));
+  CHECK(hipMalloc(&sink, TILES * SLICES * 256 * 16));
+  CHECK(hipMalloc(&flush, flush_n * 16));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, w, n, 7u);
+  CHECK(hipDeviceSynchronize());
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, flush, flush_n, 3u);
+  CHECK(hipDeviceSynchronize());
+  for (int pass = 0; pass < 2; ++pass) {
+  g_clean_flush = pass == 1;
+  printf("-- caches evicted by %s 1 GiB before each timed launch\n", g_clean_flush ? "READING" : "WRITING");
+  run<0, 2>("tile-major", w, sink, flush, flush_n);
+  run<0, 4>("tile-major", w, sink, flush, flush_n);
+  run<0, 8>("tile-major", w, sink, flush, flush_n);
+  run<1, 2>("step-major", w, sink, flush, flush_n);
+  run<1, 4>("step-major", w, sink, flush, flush_n);
+  run<1, 8>("step-major", w, sink, flush, flush_n);
+  run<2, 2>("linear", w, sink, flush, flush_n);
+  run<2, 4>("linear", w, sink, flush, flush_n);
+  run<2, 8>("linear", w, sink, flush, flush_n);
+  }
+  return 0;
+}
