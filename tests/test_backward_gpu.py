@@ -171,6 +171,82 @@ def test_nonlocal_backward_vs_torch():
         assert e < (4e-2 if n.startswith(("phi.", "g.")) else TOL), (n, e)
 
 
+@pytest.mark.parametrize("ksize,stride,cin,cout", [((1, 1, 1), (1, 1, 1), 64, 256), ((3, 1, 1), (1, 1, 1), 128, 64),
+                                                   ((1, 3, 3), (1, 2, 2), 64, 64)])
+def test_convmodule_batch_statistics_vs_torch(ksize, stride, cin, cout):
+    """ConvModule.run_train with its BatchNorm3d in TRAINING mode (the reference's I3D config: norm_eval=False,
+    lib/i3d/resnet3d.py:804-811): output, running statistics and every gradient against nn.Conv3d + nn.BatchNorm3d +
+    ReLU in f32 on the CPU (torch reference of a floating-point path; the conv output is rounded to bf16 before the
+    normalisation on the HIP side, straight-through in the reference as in the bottleneck test)."""
+    from trace_amd.resnet3d import ConvModule
+    torch.manual_seed(11 + cin)
+    pad = tuple((k - 1) // 2 for k in ksize)
+    m = ConvModule(cin, cout, ksize, stride=stride, padding=pad, bias=False, norm_cfg=dict(type='BN3d'), act_cfg=dict(type='ReLU'))
+    with torch.no_grad():
+        m.conv.weight.mul_(2.0)
+        m.bn.weight.uniform_(0.5, 1.5)
+        m.bn.bias.normal_(0, 0.3)
+    m.train()
+    x = torch.randn((2, cin, 4, 14, 14)) * 1.5 + 0.3
+    xr = x.bfloat16().float().requires_grad_(True)
+    wq = m.conv.weight + (m.conv.weight.bfloat16().float() - m.conv.weight).detach()
+    y = F.conv3d(xr, wq, None, m.conv.stride, m.conv.padding, m.conv.dilation)
+    y = y + (y.bfloat16().float() - y).detach()
+    rm, rv = m.bn.running_mean.clone(), m.bn.running_var.clone()
+    out = torch.relu(F.batch_norm(y, rm, rv, m.bn.weight, m.bn.bias, True, m.bn.momentum, m.bn.eps))
+    r = torch.randn(out.shape).bfloat16().float()
+    (out * r).sum().backward()
+    ref = {n: p.grad.clone() for n, p in m.named_parameters()}
+    gx_ref = xr.grad.clone()
+    m.zero_grad()
+    m.to(DEV)
+    xh = x.bfloat16().permute(0, 2, 3, 4, 1).contiguous().to(DEV).requires_grad_(True)
+    oh = m.run_train(xh)
+    assert rel(oh.permute(0, 4, 1, 2, 3), out.detach()) < TOL
+    assert rel(m.bn.running_mean, rm) < TOL and rel(m.bn.running_var, rv) < TOL and int(m.bn.num_batches_tracked) == 1
+    (oh.float() * r.permute(0, 2, 3, 4, 1).to(DEV)).sum().backward()
+    assert rel(xh.grad.permute(0, 4, 1, 2, 3), gx_ref) < TOL, "input gradient"
+    for n, p in m.named_parameters():
+        assert rel(p.grad, ref[n]) < TOL, (n, rel(p.grad, ref[n]))
+    # eval mode afterwards: the fold uses the statistics the training step left behind
+    m.eval()
+    with torch.no_grad():
+        ev = m.run_train(xh.detach())
+        want = torch.relu(F.batch_norm(y.detach(), rm, rv, m.bn.weight.cpu(), m.bn.bias.cpu(), False, 0.0, m.bn.eps))
+    assert rel(ev.permute(0, 4, 1, 2, 3), want) < TOL
+
+
+def test_resnet3d_train_mode_uses_batch_statistics():
+    """model.train() with the reference's config (norm_eval=False, frozen_stages=0): the stem stays in eval mode, the
+    BatchNorm3d of layers 1-4 normalise with batch statistics - running statistics move, the output differs from the
+    eval-mode forward, gradients reach every parameter behind the stem."""
+    from trace_amd.resnet3d import ResNet3d, i3d_dc5_config
+    from trace_amd.synthetic import randomize_model
+    m = ResNet3d(**i3d_dc5_config())
+    randomize_model(m, 4)
+    clip = torch.randn((2, 3, 8, 64, 64), generator=torch.Generator().manual_seed(10)) * 50
+    m.calibrate_bn(clip)
+    m.to(DEV)
+    clip = clip.to(DEV)
+    m.eval()
+    with torch.no_grad():
+        ev = m.forward_train(clip).float()
+    m.train()
+    assert not m.conv1.bn.training and m.layer1[0].conv1.bn.training and m.layer4[2].conv3.bn.training
+    before = {n: b.clone() for n, b in m.named_buffers() if n.endswith("running_mean")}
+    out = m.forward_train(clip)
+    assert bool(torch.isfinite(out.float()).all()) and rel(out.detach().float(), ev) > 1e-3
+    moved = [n for n, b in m.named_buffers() if n.endswith("running_mean") and not torch.equal(b, before[n])]
+    assert moved and all(not n.startswith("conv1.") for n in moved) and any(n.startswith("layer4.") for n in moved)
+    out.float().square().mean().backward()
+    for n, p in m.named_parameters():
+        if n.startswith("conv1."):
+            assert p.grad is None, n
+        else:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    m.eval()
+
+
 def test_resnet3d_forward_train_reaches_the_unfrozen_stages():
     """ResNet3d.forward_train with frozen_stages = 2 (lib/modeling_rel/model_builder_rel.py:166-169): same output as the
     inference path (different launch fusion, so bf16-close, not bitwise), gradients on every parameter of layer3 / layer4

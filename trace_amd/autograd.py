@@ -12,8 +12,8 @@ A convolution's two gradients are convolutions / GEMMs again, so no new device c
 
 Operands are bf16 as in the forward pass (dy is rounded to bf16), accumulation f32, weight gradients come back in f32
 for the f32 master weights.  The strided views / zero stuffing / transposes around the kernels are torch indexing and
-`ops.transpose` - plumbing, not the product's arithmetic.  Frozen-statistics BatchNorm only (the fold of ConvModule):
-batch-statistics BN (the reference config's norm_eval=False) is not implemented.
+`ops.transpose` - plumbing, not the product's arithmetic.  BatchNorm is handled by the caller (ConvModule.run_train):
+folded into the weights in eval mode, torch's batch_norm over the raw conv output in training mode.
 """
 import torch
 import torch.nn.functional as F

@@ -10,8 +10,9 @@ match the reference so its checkpoints load (`conv1.conv.weight`,
 The forward pass does not run torch convolutions: activations are kept
 channels-last bf16 (N,T,H,W,C) and every Conv3d+BN(+residual)(+ReLU) is one
 implicit-GEMM launch of libtrace_amd.so with the eval-mode BatchNorm folded into
-the packed weights.  Inference only (the reference evaluates with
-`norm_eval`/`.eval()` BN statistics); training forward raises.
+the packed weights (the reference evaluates with `norm_eval`/`.eval()` BN statistics).  `forward_train` is the
+training-side forward: convs and their gradients on the same kernels (trace_amd/autograd.py), BatchNorm folded when
+in eval mode, batch statistics when in training mode.
 """
 import torch
 import torch.nn as nn
@@ -84,12 +85,33 @@ class ConvModule(nn.Module):
                           pool_t2=pool_t2)
 
     def run_train(self, x, relu=None):
-        """`run` under autograd (trace_amd/autograd.py): the BatchNorm fold is taken differentiably from the f32
-        parameters (frozen statistics: running_mean / running_var are constants), the convolution and both of its
-        gradients run on the HIP kernels.  Gradients reach conv.weight, conv.bias, bn.weight, bn.bias and x."""
+        """`run` under autograd (trace_amd/autograd.py); the convolution and both of its gradients run on the HIP kernels.
+        BatchNorm in eval mode (norm_eval, frozen stages): the fold is taken differentiably from the f32 parameters
+        (running_mean / running_var are constants).  BatchNorm in training mode: batch statistics, see below.
+        Gradients reach conv.weight, conv.bias, bn.weight, bn.bias and x."""
         from . import autograd as tag
         w = self.conv.weight.float()
         cout = w.shape[0]
+        if self.with_norm and self.bn.training:
+            # batch statistics (the reference's I3D config trains with norm_eval=False: lib/i3d/resnet3d.py:804-811 leaves
+            # the BatchNorm3d of the unfrozen stages in training mode): the raw convolution on the HIP kernel, then
+            # torch's batch_norm over the (N T H W) positions of the channels-last result - which also moves
+            # running_mean / running_var / num_batches_tracked exactly as nn.BatchNorm3d does - and the activation
+            c = self.conv
+            y = tag.conv3d(x, w.permute(0, 2, 3, 4, 1).reshape(cout, -1), None if c.bias is None else c.bias.float(),
+                           c.kernel_size, c.stride, c.padding, c.dilation, relu=False)
+            bn = self.bn
+            if bn.momentum is None:       # cumulative moving average (nn.BatchNorm semantics)
+                factor = 1.0 / float(bn.num_batches_tracked + 1) if bn.track_running_stats else 0.0
+            else:
+                factor = bn.momentum
+            if bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            out = F.batch_norm(y.reshape(-1, cout).float(), bn.running_mean if bn.track_running_stats else None,
+                               bn.running_var if bn.track_running_stats else None, bn.weight, bn.bias, True, factor, bn.eps)
+            if self.with_activation if relu is None else relu:
+                out = torch.relu(out)
+            return out.to(torch.bfloat16).view(y.shape)
         if self.with_norm:
             scale = self.bn.weight.float() / torch.sqrt(self.bn.running_var.float() + self.bn.eps)
             shift = self.bn.bias.float() - self.bn.running_mean.float() * scale
@@ -545,8 +567,9 @@ class ResNet3d(nn.Module):
         """Training-side forward (tools/train_net_step_rel.py:580-629 reaches the backbone through
         Generalized_RCNN._forward): the stem and the stages up to `frozen_stages` (lib/i3d/resnet3d.py:746-767) run on the
         inference path without a graph, the later stages run under autograd with every conv / GEMM and its gradients on
-        the HIP kernels (`run_train`).  BatchNorm uses its running statistics everywhere (norm_eval semantics; batch
-        statistics - the reference config's norm_eval=False - are not implemented).  -> (N,T',H',W',feat_dim) bf16."""
+        the HIP kernels (`run_train`).  A BatchNorm3d in eval mode (`norm_eval=True`, frozen stages, or the whole
+        module in .eval()) uses its running statistics; in training mode (the reference config's norm_eval=False after
+        `.train()`) it normalises with batch statistics and updates the running ones.  -> (N,T',H',W',feat_dim) bf16."""
         frozen = max(self.frozen_stages, 0)
         with torch.no_grad():
             x = self._run_stem(x, in_ntchw)
