@@ -66,6 +66,26 @@ int trace_roi_pool_bwd_f32(const float* grad, const int32_t* argmax,
                            int pooled_w, int B, int C, int H, int W,
                            float* grad_input, trace_stream_t stream);
 
+/* The double half of the reference's dtype dispatch (AT_DISPATCH_FLOATING_TYPES: cuda/ROIAlign_cuda.cu:283,330,
+ * cuda/ROIPool_cuda.cu:129,178, cpu/ROIAlign_cpu.cpp:243): the four ops above with float64 data and float64 rois
+ * (the reference reads the rois in the input's dtype), same arguments, same rules. */
+int trace_roi_align_fwd_f64(const double* input, int B, int C, int H, int W,
+                            const double* rois, int K, float spatial_scale,
+                            int pooled_h, int pooled_w, int sampling_ratio,
+                            double* out, trace_stream_t stream);
+int trace_roi_align_bwd_f64(const double* grad, const double* rois, int K,
+                            float spatial_scale, int pooled_h, int pooled_w,
+                            int B, int C, int H, int W, int sampling_ratio,
+                            double* grad_input, trace_stream_t stream);
+int trace_roi_pool_fwd_f64(const double* input, int B, int C, int H, int W,
+                           const double* rois, int K, float spatial_scale,
+                           int pooled_h, int pooled_w, double* out,
+                           int32_t* argmax, trace_stream_t stream);
+int trace_roi_pool_bwd_f64(const double* grad, const int32_t* argmax,
+                           const double* rois, int K, int pooled_h,
+                           int pooled_w, int B, int C, int H, int W,
+                           double* grad_input, trace_stream_t stream);
+
 /* MI355X-native layout variant of roi_align_forward used inside the fused
  * pipeline: input (B,H,W,C) bf16 channels-last, out (K,PH,PW,C) bf16; same
  * sampling rule as above, f32 accumulation.  Replaces the per-call

@@ -33,41 +33,53 @@ def _f(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _real(inp):
+    """(numpy dtype, symbol suffix, scale ctype) of a ROI call: float64 data take the _f64 build of roi_oracle.inc (the
+    reference passes spatial_scale as a C float whatever the tensor type: it is rounded to float32 first)."""
+    if np.asarray(inp).dtype == np.float64:
+        return np.float64, "_f64", lambda s: ctypes.c_double(float(np.float32(s)))
+    return np.float32, "", lambda s: ctypes.c_float(s)
+
+
 def roi_align_fwd(inp, rois, scale, ph, pw, sr):
-    inp, rois = _f(inp), _f(rois)
+    dt, sfx, sc = _real(inp)
+    inp, rois = np.ascontiguousarray(inp, dt), np.ascontiguousarray(rois, dt)
     B, C, H, W = inp.shape
     K = rois.shape[0]
-    out = np.empty((K, C, ph, pw), np.float32)
+    out = np.empty((K, C, ph, pw), dt)
     if out.size:
-        lib().oracle_roi_align_fwd(_p(inp), B, C, H, W, _p(rois), K, ctypes.c_float(scale), ph, pw, sr, _p(out))
+        getattr(lib(), "oracle_roi_align_fwd" + sfx)(_p(inp), B, C, H, W, _p(rois), K, sc(scale), ph, pw, sr, _p(out))
     return out
 
 
 def roi_align_bwd(grad, rois, scale, ph, pw, B, C, H, W, sr):
-    grad, rois = _f(grad), _f(rois)
-    gin = np.zeros((B, C, H, W), np.float32)
+    dt, sfx, sc = _real(grad)
+    grad, rois = np.ascontiguousarray(grad, dt), np.ascontiguousarray(rois, dt)
+    gin = np.zeros((B, C, H, W), dt)
     if grad.size:
-        lib().oracle_roi_align_bwd(_p(grad), _p(rois), rois.shape[0], ctypes.c_float(scale), ph, pw, B, C, H, W, sr, _p(gin))
+        getattr(lib(), "oracle_roi_align_bwd" + sfx)(_p(grad), _p(rois), rois.shape[0], sc(scale), ph, pw, B, C, H, W, sr, _p(gin))
     return gin
 
 
 def roi_pool_fwd(inp, rois, scale, ph, pw):
-    inp, rois = _f(inp), _f(rois)
+    dt, sfx, sc = _real(inp)
+    inp, rois = np.ascontiguousarray(inp, dt), np.ascontiguousarray(rois, dt)
     B, C, H, W = inp.shape
     K = rois.shape[0]
-    out = np.empty((K, C, ph, pw), np.float32)
+    out = np.empty((K, C, ph, pw), dt)
     am = np.zeros((K, C, ph, pw), np.int32)
     if out.size:
-        lib().oracle_roi_pool_fwd(_p(inp), B, C, H, W, _p(rois), K, ctypes.c_float(scale), ph, pw, _p(out), _p(am))
+        getattr(lib(), "oracle_roi_pool_fwd" + sfx)(_p(inp), B, C, H, W, _p(rois), K, sc(scale), ph, pw, _p(out), _p(am))
     return out, am
 
 
 def roi_pool_bwd(grad, argmax, rois, ph, pw, B, C, H, W):
-    grad, rois = _f(grad), _f(rois)
+    dt, sfx, _ = _real(grad)
+    grad, rois = np.ascontiguousarray(grad, dt), np.ascontiguousarray(rois, dt)
     argmax = np.ascontiguousarray(argmax, np.int32)
-    gin = np.zeros((B, C, H, W), np.float32)
+    gin = np.zeros((B, C, H, W), dt)
     if grad.size:
-        lib().oracle_roi_pool_bwd(_p(grad), _p(argmax), _p(rois), rois.shape[0], ph, pw, B, C, H, W, _p(gin))
+        getattr(lib(), "oracle_roi_pool_bwd" + sfx)(_p(grad), _p(argmax), _p(rois), rois.shape[0], ph, pw, B, C, H, W, _p(gin))
     return gin
 
 

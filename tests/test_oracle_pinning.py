@@ -7,6 +7,22 @@ from oracle import c_oracle, np_oracle
 from conftest import synth_boxes, distinct_scores
 
 
+def test_roi_align_fwd_f64_matches_reference_golden(golden):
+    """The double half of the reference's dtype dispatch (cpu/ROIAlign_cpu.cpp:243): the oracle built over double
+    reproduces the outputs of the reference's own compiled code bit for bit (tools/make_goldens_r3.py)."""
+    g = golden("roi_align_fwd_f64.npz")
+    feat, rois = g["feat"], g["rois"]
+    assert feat.dtype == np.float64 and rois.dtype == np.float64
+    for sr in (0, 2):
+        for scale in (1.0 / 16, 0.25):
+            out = c_oracle.roi_align_fwd(feat, rois, scale, 7, 7, sr)
+            assert out.dtype == np.float64 and np.array_equal(out, g["out_sr%d_s%g" % (sr, scale)]), (sr, scale)
+    assert np.array_equal(c_oracle.roi_align_fwd(feat, rois, 1.0 / 16, 5, 3, 0), g["out_5x3_sr0"])
+    # a float32 computation does not reproduce them: the fixture does test the double path
+    lo = c_oracle.roi_align_fwd(feat.astype(np.float32), rois.astype(np.float32), 1.0 / 16, 7, 7, 0)
+    assert not np.array_equal(lo.astype(np.float64), g["out_sr0_s0.0625"])
+
+
 def test_roi_align_fwd_matches_reference_golden(golden):
     g = golden("roi_align_fwd.npz")
     feat, rois = g["feat"], g["rois"]

@@ -108,6 +108,46 @@ def test_roi_align_avg_nhwc_bf16(sr):
     np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=2e-2, atol=1e-2)
 
 
+def test_roi_ops_float64_dispatch(golden):
+    """The reference's extension dispatches its ROI ops on float and double (ROIAlign_cuda.cu:283,330, ROIPool_cuda.cu:
+    129,178): `_C.roi_align_forward` in float64 is bit-exact against the golden of the reference's own compiled CPU code
+    and against the oracle on fresh inputs; backward and ROIPool against the double oracle (sums of atomics: 1e-12);
+    mixed dtypes and half precision are refused as a RuntimeError."""
+    from trace_amd import _C
+    g = golden("roi_align_fwd_f64.npz")
+    feat, rois = torch.from_numpy(g["feat"]).to(DEV), torch.from_numpy(g["rois"]).to(DEV)
+    for sr in (0, 2):
+        for scale in (1.0 / 16, 0.25):
+            out = _C.roi_align_forward(feat, rois, scale, 7, 7, sr)
+            assert out.dtype == torch.float64 and np.array_equal(out.cpu().numpy(), g["out_sr%d_s%g" % (sr, scale)]), (sr, scale)
+    assert np.array_equal(_C.roi_align_forward(feat, rois, 1.0 / 16, 5, 3, 0).cpu().numpy(), g["out_5x3_sr0"])
+    rng = np.random.default_rng(64)
+    x = rng.standard_normal((3, 5, 20, 17))
+    r = _rois(rng, 30, 3).astype(np.float64) + rng.uniform(0, 1e-6, (30, 5)) * np.array([0, 1, 1, 1, 1.0])
+    xd, rd = torch.from_numpy(x).to(DEV), torch.from_numpy(r).to(DEV)
+    for sr in (0, 3):
+        assert np.array_equal(_C.roi_align_forward(xd, rd, 1 / 16., 7, 7, sr).cpu().numpy(), c_oracle.roi_align_fwd(x, r, 1 / 16., 7, 7, sr))
+        gy = rng.standard_normal((30, 5, 7, 7))
+        gin = _C.roi_align_backward(torch.from_numpy(gy).to(DEV), rd, 1 / 16., 7, 7, 3, 5, 20, 17, sr)
+        assert gin.dtype == torch.float64
+        np.testing.assert_allclose(gin.cpu().numpy(), c_oracle.roi_align_bwd(gy, r, 1 / 16., 7, 7, 3, 5, 20, 17, sr), rtol=1e-12, atol=1e-12)
+    po, am = _C.roi_pool_forward(xd, rd, 1 / 16., 7, 7)
+    wo, wa = c_oracle.roi_pool_fwd(x, r, 1 / 16., 7, 7)
+    assert po.dtype == torch.float64 and np.array_equal(po.cpu().numpy(), wo) and np.array_equal(am.cpu().numpy(), wa)
+    gy = rng.standard_normal((30, 5, 7, 7))
+    gp = _C.roi_pool_backward(torch.from_numpy(gy).to(DEV), xd, rd, am, 1 / 16., 7, 7, 3, 5, 20, 17)
+    np.testing.assert_allclose(gp.cpu().numpy(), c_oracle.roi_pool_bwd(gy, wa, r, 7, 7, 3, 5, 20, 17), rtol=1e-12, atol=1e-12)
+    with pytest.raises(RuntimeError):
+        _C.roi_align_forward(xd, rd.float(), 1 / 16., 7, 7, 0)
+    with pytest.raises(RuntimeError):
+        _C.roi_align_forward(xd.half(), rd.half(), 1 / 16., 7, 7, 0)
+    # the layer modules pass the dtype through (roi_layers/roi_align.py:11-59): gradient check in double
+    from trace_amd.roi_layers import ROIAlign
+    xs = torch.from_numpy(rng.standard_normal((1, 2, 8, 8))).to(DEV).requires_grad_(True)
+    rr = torch.tensor([[0, 8.0, 12.0, 90.0, 100.0], [0, 20.0, 4.0, 60.0, 70.0]], dtype=torch.float64, device=DEV)
+    assert torch.autograd.gradcheck(lambda t: ROIAlign((3, 3), 1 / 16., 2)(t, rr), (xs,), eps=1e-6, atol=1e-8)
+
+
 def test_roi_align_full_size_constant_property():
     """BASELINE cfg5-sized call (2100 rois x 2048 ch): a constant map pools to the constant."""
     from trace_amd import _C

@@ -2,7 +2,7 @@
 (Detectron_pytorch/lib/model/csrc/vision.cpp:7-13) on top of libtrace_amd.so.
 
 Same function names, argument order and error behaviour (RuntimeError) as the
-pybind module; tensors must be float32 and live on the GPU.
+pybind module; tensors live on the GPU; the ROI ops take float32 or float64 (the reference's dtype dispatch), NMS float32.
 """
 import torch
 
@@ -16,71 +16,83 @@ def _f32(t, name):
     return t.contiguous()  # ROIAlign_cuda.cu:286,294
 
 
+def _floating(t, name, like=None):
+    """The reference dispatches these ops on float / double (AT_DISPATCH_FLOATING_TYPES) and reads every tensor of a call
+    in the input's dtype: float32 or float64 here, all arguments alike."""
+    L.require_gpu(t)
+    if t.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("%s must be float32 or float64 (got %s)" % (name, t.dtype))
+    if like is not None and t.dtype != like.dtype:
+        raise RuntimeError("%s is %s, the call's data are %s" % (name, t.dtype, like.dtype))
+    return t.contiguous()  # ROIAlign_cuda.cu:286,294
+
+
+def _sfx(t):
+    return "f64" if t.dtype == torch.float64 else "f32"
+
+
 def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio):
     """vision.cpp:9 / ROIAlign.h:11-25 — returns (K,C,PH,PW)."""
-    input = _f32(input, "input")
-    rois = _f32(rois, "rois")
+    input = _floating(input, "input")
+    rois = _floating(rois, "rois", input)
     if rois.dim() != 2 or rois.size(1) != 5:
         raise RuntimeError("rois must be (K,5)")
     B, C, H, W = input.shape
     K = rois.size(0)
-    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
     if out.numel() == 0:
         return out
     with torch.cuda.device(input.device):
-        L.check(L.lib().trace_roi_align_fwd_f32(L.ptr(input), B, C, H, W, L.ptr(rois), K,
-                                                float(spatial_scale), int(pooled_height),
-                                                int(pooled_width), int(sampling_ratio), L.ptr(out),
-                                                L.stream()), "roi_align_forward")
+        fn = getattr(L.lib(), "trace_roi_align_fwd_" + _sfx(input))
+        L.check(fn(L.ptr(input), B, C, H, W, L.ptr(rois), K, float(spatial_scale), int(pooled_height),
+                   int(pooled_width), int(sampling_ratio), L.ptr(out), L.stream()), "roi_align_forward")
     return out
 
 
 def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels,
                        height, width, sampling_ratio):
     """vision.cpp:10 / ROIAlign.h:27-45 — returns (B,C,H,W)."""
-    grad = _f32(grad, "grad")
-    rois = _f32(rois, "rois")
-    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    grad = _floating(grad, "grad")
+    rois = _floating(rois, "rois", grad)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     with torch.cuda.device(grad.device):
-        L.check(L.lib().trace_roi_align_bwd_f32(L.ptr(grad), L.ptr(rois), rois.size(0),
-                                                float(spatial_scale), int(pooled_height),
-                                                int(pooled_width), int(batch_size), int(channels),
-                                                int(height), int(width), int(sampling_ratio),
-                                                L.ptr(gin), L.stream()), "roi_align_backward")
+        fn = getattr(L.lib(), "trace_roi_align_bwd_" + _sfx(grad))
+        L.check(fn(L.ptr(grad), L.ptr(rois), rois.size(0), float(spatial_scale), int(pooled_height),
+                   int(pooled_width), int(batch_size), int(channels), int(height), int(width),
+                   int(sampling_ratio), L.ptr(gin), L.stream()), "roi_align_backward")
     return gin
 
 
 def roi_pool_forward(input, rois, spatial_scale, pooled_height, pooled_width):
     """vision.cpp:11 / ROIPool.h:11-25 — returns (output, argmax int32)."""
-    input = _f32(input, "input")
-    rois = _f32(rois, "rois")
+    input = _floating(input, "input")
+    rois = _floating(rois, "rois", input)
     B, C, H, W = input.shape
     K = rois.size(0)
-    out = torch.empty((K, C, pooled_height, pooled_width), dtype=torch.float32, device=input.device)
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=input.dtype, device=input.device)
     argmax = torch.zeros((K, C, pooled_height, pooled_width), dtype=torch.int32, device=input.device)
     if out.numel() == 0:
         return out, argmax
     with torch.cuda.device(input.device):
-        L.check(L.lib().trace_roi_pool_fwd_f32(L.ptr(input), B, C, H, W, L.ptr(rois), K,
-                                               float(spatial_scale), int(pooled_height),
-                                               int(pooled_width), L.ptr(out), L.ptr(argmax),
-                                               L.stream()), "roi_pool_forward")
+        fn = getattr(L.lib(), "trace_roi_pool_fwd_" + _sfx(input))
+        L.check(fn(L.ptr(input), B, C, H, W, L.ptr(rois), K, float(spatial_scale), int(pooled_height),
+                   int(pooled_width), L.ptr(out), L.ptr(argmax), L.stream()), "roi_pool_forward")
     return out, argmax
 
 
 def roi_pool_backward(grad, input, rois, argmax, spatial_scale, pooled_height, pooled_width,
                       batch_size, channels, height, width):
     """vision.cpp:12 / ROIPool.h:27-46 — returns (B,C,H,W)."""
-    grad = _f32(grad, "grad")
-    rois = _f32(rois, "rois")
+    grad = _floating(grad, "grad")
+    rois = _floating(rois, "rois", grad)
     L.require_gpu(argmax)
     argmax = argmax.contiguous()
-    gin = torch.empty((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device)
     with torch.cuda.device(grad.device):
-        L.check(L.lib().trace_roi_pool_bwd_f32(L.ptr(grad), L.ptr(argmax), L.ptr(rois), rois.size(0),
-                                               int(pooled_height), int(pooled_width), int(batch_size),
-                                               int(channels), int(height), int(width), L.ptr(gin),
-                                               L.stream()), "roi_pool_backward")
+        fn = getattr(L.lib(), "trace_roi_pool_bwd_" + _sfx(grad))
+        L.check(fn(L.ptr(grad), L.ptr(argmax), L.ptr(rois), rois.size(0), int(pooled_height), int(pooled_width),
+                   int(batch_size), int(channels), int(height), int(width), L.ptr(gin), L.stream()),
+                "roi_pool_backward")
     return gin
 
 

@@ -33,6 +33,10 @@ SIGNATURES = {
     "trace_roi_align_bwd_f32": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "trace_roi_pool_fwd_f32": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, P, P, P]),
     "trace_roi_pool_bwd_f32": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "trace_roi_align_fwd_f64": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
+    "trace_roi_align_bwd_f64": (c_int, [P, P, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "trace_roi_pool_fwd_f64": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, P, P, P]),
+    "trace_roi_pool_bwd_f64": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     "trace_roi_align_fwd_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_roi_align_avg_nhwc_bf16": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_float, c_int, c_int, c_int, P, P]),
     "trace_nl_pool_split_bf16": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),

@@ -210,6 +210,174 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_f32_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The same four NCHW ops in float64: the reference's extension dispatches on float / double
+// (AT_DISPATCH_FLOATING_TYPES, ROIAlign_cuda.cu:283,330; ROIPool_cuda.cu:129,178; ROIAlign_cpu.cpp:243), rois in the
+// input's dtype.  Kept apart from the float32 kernels above (whose bit-exact contract then cannot move): the same
+// statements with double in place of float, one thread per output element.
+// ---------------------------------------------------------------------------
+struct RoiGeomD {
+  int batch;
+  double start_w, start_h, bin_w, bin_h;
+  int grid_h, grid_w;
+  double count;
+};
+__device__ __forceinline__ RoiGeomD roi_geom_d(const double* r, double scale, int PH, int PW, int sr, int B) {
+  RoiGeomD g;
+  g.batch = min(max((int)r[0], 0), B - 1);
+  g.start_w = r[1] * scale;
+  g.start_h = r[2] * scale;
+  const double end_w = r[3] * scale, end_h = r[4] * scale;
+  const double roi_w = fmax(end_w - g.start_w, 1.0), roi_h = fmax(end_h - g.start_h, 1.0);
+  g.bin_h = roi_h / (double)PH;
+  g.bin_w = roi_w / (double)PW;
+  g.grid_h = (sr > 0) ? sr : (int)ceil(roi_h / (double)PH);
+  g.grid_w = (sr > 0) ? sr : (int)ceil(roi_w / (double)PW);
+  g.count = (double)(g.grid_h * g.grid_w);
+  return g;
+}
+struct BilinD {
+  int p1, p2, p3, p4;
+  double w1, w2, w3, w4;
+  bool valid;
+};
+__device__ __forceinline__ BilinD bilin_setup_d(double y, double x, int H, int W) {
+  BilinD b;
+  if (y < -1.0 || y > (double)H || x < -1.0 || x > (double)W) {
+    b.p1 = b.p2 = b.p3 = b.p4 = 0;
+    b.w1 = b.w2 = b.w3 = b.w4 = 0.0;
+    b.valid = false;
+    return b;
+  }
+  if (y <= 0.0) y = 0.0;
+  if (x <= 0.0) x = 0.0;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) {
+    y_high = y_low = H - 1;
+    y = (double)y_low;
+  } else {
+    y_high = y_low + 1;
+  }
+  if (x_low >= W - 1) {
+    x_high = x_low = W - 1;
+    x = (double)x_low;
+  } else {
+    x_high = x_low + 1;
+  }
+  const double ly = y - (double)y_low, lx = x - (double)x_low;
+  const double hy = 1.0 - ly, hx = 1.0 - lx;
+  b.w1 = hy * hx;
+  b.w2 = hy * lx;
+  b.w3 = ly * hx;
+  b.w4 = ly * lx;
+  b.p1 = y_low * W + x_low;
+  b.p2 = y_low * W + x_high;
+  b.p3 = y_high * W + x_low;
+  b.p4 = y_high * W + x_high;
+  b.valid = true;
+  return b;
+}
+__device__ __forceinline__ double sample_coord_d(double start, int p, double bin, int i, int grid) {
+  return start + (double)p * bin + (double)((float)i + .5f) * bin / (double)grid;   // static_cast<T>(iy + .5f)
+}
+
+__global__ __launch_bounds__(256) void roi_align_fwd_f64_kernel(
+    long long nthreads, const double* __restrict__ in, double scale, int B, int C, int H, int W,
+    int PH, int PW, int sr, const double* __restrict__ rois, double* __restrict__ out) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW), ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const RoiGeomD g = roi_geom_d(rois + (long long)n * 5, scale, PH, PW, sr, B);
+    const double* plane = in + ((long long)g.batch * C + c) * H * W;
+    double acc = 0.0;
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      const double y = sample_coord_d(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        const double x = sample_coord_d(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        const BilinD b = bilin_setup_d(y, x, H, W);
+        acc += b.w1 * plane[b.p1] + b.w2 * plane[b.p2] + b.w3 * plane[b.p3] + b.w4 * plane[b.p4];
+      }
+    }
+    out[index] = acc / g.count;
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd_f64_kernel(
+    long long nthreads, const double* __restrict__ grad, double scale, int B, int C, int H, int W,
+    int PH, int PW, int sr, double* __restrict__ gin, const double* __restrict__ rois) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW), ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const RoiGeomD g = roi_geom_d(rois + (long long)n * 5, scale, PH, PW, sr, B);
+    double* plane = gin + ((long long)g.batch * C + c) * H * W;
+    const double top = grad[index];
+    for (int iy = 0; iy < g.grid_h; ++iy) {
+      const double y = sample_coord_d(g.start_h, ph, g.bin_h, iy, g.grid_h);
+      for (int ix = 0; ix < g.grid_w; ++ix) {
+        const double x = sample_coord_d(g.start_w, pw, g.bin_w, ix, g.grid_w);
+        const BilinD b = bilin_setup_d(y, x, H, W);
+        if (b.valid) {
+          atomicAdd(plane + b.p1, top * b.w1 / g.count);
+          atomicAdd(plane + b.p2, top * b.w2 / g.count);
+          atomicAdd(plane + b.p3, top * b.w3 / g.count);
+          atomicAdd(plane + b.p4, top * b.w4 / g.count);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_pool_fwd_f64_kernel(
+    long long nthreads, const double* __restrict__ in, double scale, int B, int C, int H, int W,
+    int PH, int PW, const double* __restrict__ rois, double* __restrict__ out, int32_t* __restrict__ argmax) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW), ph = (int)((index / PW) % PH);
+    const int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const double* r = rois + (long long)n * 5;
+    const int b = min(max((int)r[0], 0), B - 1);
+    const int rsw = (int)round(r[1] * scale), rsh = (int)round(r[2] * scale);
+    const int rew = (int)round(r[3] * scale), reh = (int)round(r[4] * scale);
+    const int rw = max(rew - rsw + 1, 1), rh = max(reh - rsh + 1, 1);
+    const double bin_h = (double)rh / (double)PH, bin_w = (double)rw / (double)PW;
+    int hstart = (int)floor((double)ph * bin_h), wstart = (int)floor((double)pw * bin_w);
+    int hend = (int)ceil((double)(ph + 1) * bin_h), wend = (int)ceil((double)(pw + 1) * bin_w);
+    hstart = min(max(hstart + rsh, 0), H);
+    hend = min(max(hend + rsh, 0), H);
+    wstart = min(max(wstart + rsw, 0), W);
+    wend = min(max(wend + rsw, 0), W);
+    const bool is_empty = (hend <= hstart) || (wend <= wstart);
+    double maxval = is_empty ? 0.0 : -3.402823466e+38;   // -FLT_MAX for every dtype (ROIPool_cuda.cu:59)
+    int maxidx = -1;
+    const double* plane = in + ((long long)b * C + c) * H * W;
+    for (int h = hstart; h < hend; ++h)
+      for (int w = wstart; w < wend; ++w) {
+        const int bi = h * W + w;
+        const double v = plane[bi];
+        if (v > maxval) {
+          maxval = v;
+          maxidx = bi;
+        }
+      }
+    out[index] = maxval;
+    argmax[index] = maxidx;
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_pool_bwd_f64_kernel(
+    long long nthreads, const double* __restrict__ grad, const int32_t* __restrict__ argmax, int B,
+    int C, int H, int W, int PH, int PW, double* __restrict__ gin, const double* __restrict__ rois) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < nthreads;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int c = (int)((index / PW / PH) % C), n = (int)(index / PW / PH / C);
+    const int b = min(max((int)rois[(long long)n * 5], 0), B - 1);
+    const int am = argmax[index];
+    if (am != -1) atomicAdd(gin + ((long long)b * C + c) * H * W + am, grad[index]);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Forward, channels-last bf16: input (B,H,W,C), out (K,PH*PW,C).
 // One workgroup per (roi, bin); lane owns 8 consecutive channels (16 B) so each
 // corner read and the output write are 1 KiB-per-wave coalesced accesses; the
@@ -837,6 +1005,68 @@ extern "C" int trace_roi_pool_bwd_f32(const float* grad, const int32_t* argmax, 
   hipLaunchKernelGGL(roi_pool_bwd_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
                      n, grad, argmax, B, C, H, W, pooled_h, pooled_w, grad_input, rois);
   return check_launch("roi_pool_bwd_f32");
+}
+
+// float64 forms of the four NCHW ops (see the kernels): same arguments, double data and rois
+extern "C" int trace_roi_align_fwd_f64(const double* input, int B, int C, int H, int W, const double* rois, int K,
+                                       float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                       double* out, trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0,
+                "roi_align_fwd_f64: bad shape B=%d C=%d H=%d W=%d K=%d", B, C, H, W, K);
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(input && rois && out, "roi_align_fwd_f64: null pointer");
+  hipLaunchKernelGGL(roi_align_fwd_f64_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, input, (double)spatial_scale, B, C, H, W, pooled_h, pooled_w, sampling_ratio, rois, out);
+  return check_launch("roi_align_fwd_f64");
+}
+
+extern "C" int trace_roi_align_bwd_f64(const double* grad, const double* rois, int K, float spatial_scale,
+                                       int pooled_h, int pooled_w, int B, int C, int H, int W, int sampling_ratio,
+                                       double* grad_input, trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0, "roi_align_bwd_f64: bad shape");
+  size_t gin_bytes = (size_t)B * C * H * W * sizeof(double);
+  if (gin_bytes) {
+    TRACE_REQUIRE(grad_input, "roi_align_bwd_f64: null grad_input");
+    hipError_t e = hipMemsetAsync(grad_input, 0, gin_bytes, (hipStream_t)stream);
+    TRACE_REQUIRE(e == hipSuccess, "roi_align_bwd_f64: memset: %s", hipGetErrorString(e));
+  }
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(grad && rois, "roi_align_bwd_f64: null pointer");
+  hipLaunchKernelGGL(roi_align_bwd_f64_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, grad, (double)spatial_scale, B, C, H, W, pooled_h, pooled_w, sampling_ratio, grad_input, rois);
+  return check_launch("roi_align_bwd_f64");
+}
+
+extern "C" int trace_roi_pool_fwd_f64(const double* input, int B, int C, int H, int W, const double* rois, int K,
+                                      float spatial_scale, int pooled_h, int pooled_w, double* out, int32_t* argmax,
+                                      trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && pooled_h > 0 && pooled_w > 0, "roi_pool_fwd_f64: bad shape");
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(input && rois && out && argmax, "roi_pool_fwd_f64: null pointer");
+  hipLaunchKernelGGL(roi_pool_fwd_f64_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, input, (double)spatial_scale, B, C, H, W, pooled_h, pooled_w, rois, out, argmax);
+  return check_launch("roi_pool_fwd_f64");
+}
+
+extern "C" int trace_roi_pool_bwd_f64(const double* grad, const int32_t* argmax, const double* rois, int K,
+                                      int pooled_h, int pooled_w, int B, int C, int H, int W, double* grad_input,
+                                      trace_stream_t stream) {
+  TRACE_REQUIRE(B >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0, "roi_pool_bwd_f64: bad shape");
+  size_t gin_bytes = (size_t)B * C * H * W * sizeof(double);
+  if (gin_bytes) {
+    TRACE_REQUIRE(grad_input, "roi_pool_bwd_f64: null grad_input");
+    hipError_t e = hipMemsetAsync(grad_input, 0, gin_bytes, (hipStream_t)stream);
+    TRACE_REQUIRE(e == hipSuccess, "roi_pool_bwd_f64: memset: %s", hipGetErrorString(e));
+  }
+  long long n = (long long)K * C * pooled_h * pooled_w;
+  if (n == 0) return 0;
+  TRACE_REQUIRE(grad && argmax && rois, "roi_pool_bwd_f64: null pointer");
+  hipLaunchKernelGGL(roi_pool_bwd_f64_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                     n, grad, argmax, B, C, H, W, pooled_h, pooled_w, grad_input, rois);
+  return check_launch("roi_pool_bwd_f64");
 }
 
 extern "C" int trace_roi_align_fwd_nhwc_bf16(const uint16_t* input, int B, int H, int W, int C,
