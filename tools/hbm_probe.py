@@ -1,4 +1,4 @@
-"""What HBM rate do plain streaming kernels reach on this GPU?  (yardstick for the weight-streaming FCs: fc1 reads
+"""Measured ceilings of this GPU beside the vendor figures.  What HBM rate do plain streaming kernels reach?  (yardstick for the weight-streaming FCs: fc1 reads
 616 MB of weights per step).  Times stock torch kernels from a captured graph: a read-only reduction, a copy, a fill."""
 import torch
 
@@ -37,3 +37,11 @@ for mb in (616, 2048):
     print("%5d MB  copy            %7.1f us  %5.2f TB/s (read + write)" % (mb, t * 1e6, 4 * n / t * 1e-12))
     t = timeit(lambda: y.fill_(0))
     print("%5d MB  fill            %7.1f us  %5.2f TB/s" % (mb, t * 1e6, 2 * n / t * 1e-12))
+
+# the matrix cores' measured ceiling on a shape that fills them (vendor GEMM, bf16 in, f32 accumulate)
+for n in (4096, 8192):
+    a = torch.randn((n, n), device=dev).to(torch.bfloat16)
+    b = torch.randn((n, n), device=dev).to(torch.bfloat16)
+    c = torch.empty((n, n), dtype=torch.bfloat16, device=dev)
+    t = timeit(lambda: torch.matmul(a, b, out=c), iters=5)
+    print("matmul %d^3 bf16     %7.1f us  %6.0f TFLOP/s" % (n, t * 1e6, 2.0 * n ** 3 / t * 1e-12))
