@@ -26,6 +26,9 @@
 constexpr int TILES = 24, KSTEPS = 1568, SLICES = 21, PER = 75;   // 21 * 75 = 1575 >= 1568
 constexpr int BLOCK = 16384;
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// MODE 3: tile-major order with NON-TEMPORAL loads (do streaming hints change the rate behind dirty caches?)
 template <int MODE, int DEPTH>
 __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ w, uint4* __restrict__ sink) {
   const int g = blockIdx.x;
@@ -38,13 +41,20 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ w
     for (int d = 0; d < DEPTH; ++d) {
       const int k = min(ks + d, ks1 - 1);
       long long blk;
-      if (MODE == 0) blk = (long long)tile * KSTEPS + k;
+      if (MODE == 0 || MODE == 3) blk = (long long)tile * KSTEPS + k;
       else if (MODE == 1) blk = (long long)k * TILES + tile;
       else blk = (long long)(k - ks0) * (TILES * SLICES) + g;
       if (MODE == 2 && blk >= (long long)TILES * KSTEPS) blk = g;
       const uint4* p = w + blk * (BLOCK / 16) + threadIdx.x;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) v[d][i] = p[i * 256];
+      for (int i = 0; i < 4; ++i) {
+        if (MODE == 3) {
+          const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p + i * 256));
+          v[d][i] = make_uint4(t.x, t.y, t.z, t.w);
+        } else {
+          v[d][i] = p[i * 256];
+        }
+      }
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
@@ -97,7 +107,7 @@ static void run(const char* name, const uint4* w, uint4* sink, uint4* flush, lon
     if (r) { best = ms < best ? ms : best; sum += ms; }
   }
   const double bytes = (double)TILES * KSTEPS * BLOCK;
-  printf("%-11s depth %d  best %7.1f us  mean %7.1f us  %5.2f TB/s\n", name, DEPTH, best * 1e3, sum / (reps - 1) * 1e3,
+  printf("%-13s depth %d  best %7.1f us  mean %7.1f us  %5.2f TB/s\n", name, DEPTH, best * 1e3, sum / (reps - 1) * 1e3,
          bytes / (best * 1e-3) * 1e-12);
 }
 
@@ -118,6 +128,8 @@ int main() {
   run<0, 2>("tile-major", w, sink, flush, flush_n);
   run<0, 4>("tile-major", w, sink, flush, flush_n);
   run<0, 8>("tile-major", w, sink, flush, flush_n);
+  run<3, 2>("tile-major nt", w, sink, flush, flush_n);
+  run<3, 4>("tile-major nt", w, sink, flush, flush_n);
   run<1, 2>("step-major", w, sink, flush, flush_n);
   run<1, 4>("step-major", w, sink, flush, flush_n);
   run<1, 8>("step-major", w, sink, flush, flush_n);

@@ -72,6 +72,7 @@ struct IgemmParams {
   float u8_mean[3];
   int dry;           // 1: plan only (trace_*_workspace_bytes): launch nothing, leave the split-K scratch the plan wants in g_dry_bytes
   int w_tiled;       // 1: `w` is pre-tiled (TRACE_EPI_WTILED): [Cout/128][K/64] blocks of 128 rows x 64 k, LDS image order
+  int w_stream;      // 1: every weight block is read by exactly one workgroup (one position tile): non-temporal loads
 };
 
 constexpr int BK = 64;
@@ -105,6 +106,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ void glds16(const void* g, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+// The same with the NON-TEMPORAL cache policy (aux bit 1 = nt on gfx940+): for operands streamed from HBM exactly once -
+// the weights of the 100352-wide FCs.  A plain load allocates in the memory-side cache and, behind kernels that
+// wrote, pays for the write-back of the dirty lines it evicts: tools/stream_probe.hip reads fc1's 616 MB at 3.4 TB/s
+// with plain loads behind a writer (6.1 TB/s on clean caches) and at 6.8 TB/s with nt loads in either state.
+__device__ __forceinline__ void glds16_nt(const void* g, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 2);
 }
 
 // cout offset (inside a 32-cout group) held by MFMA row `rho` of the even/odd fragment of a pair
@@ -608,6 +616,7 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
 
   const char* ap[WM];
   int a_step = 2 * BK;     // bytes a weight pointer advances per K-step
+  const bool w_stream = p.w_stream != 0;
   if (p.w_tiled) {
     // pre-tiled weights (TC == 128): K-step ks of cout tile tile_n is ONE contiguous 16 KiB block already in the
     // swizzled LDS image order, so a wave instruction reads 1 KiB of consecutive addresses (DRAM-page friendly:
@@ -730,10 +739,18 @@ __global__ __launch_bounds__(256) void igemm3_bf16_kernel(const IgemmParams p) {
       for (int i = 0; i < WN; ++i) glds16(lane_tail ? zero : bp[i], b + i * 4096);
       return;
     }
+    if (DENSE && w_stream) {   // uniform
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      glds16(ap[i], a + i * 4096);
-      ap[i] += a_step;
+      for (int i = 0; i < WM; ++i) {
+        glds16_nt(ap[i], a + i * 4096);
+        ap[i] += a_step;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        glds16(ap[i], a + i * 4096);
+        ap[i] += a_step;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WN; ++i) {
@@ -1819,6 +1836,9 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s, int nst_req, int
     return 0;
   }
   p.xcd_slices = (p.ksplit >= 8 && p.ksplit % 8 == 0 && batch == 1) ? 1 : 0;
+  // weight streaming (pre-tiled weights, all positions in one tile): each weight byte is fetched once - non-temporal
+  static const bool no_nt = getenv("TRACE_NO_WSTREAM_NT") != nullptr;   // A/B measurements
+  p.w_stream = (p.w_tiled && p.tiles_m == 1 && batch == 1 && !no_nt) ? 1 : 0;
   const dim3 grid((unsigned)nblk, p.ksplit, batch);
   // ring depth.  v2 main loop: 2 stages (most workgroups per CU).  v3: the leaner K loop is latency-bound
   // when few workgroups share a CU, so the ring goes to 3 (4 for single-workgroup-per-CU grids) whenever
