@@ -918,6 +918,11 @@ constexpr int ST_KSTEPS = (ST_KT * ST_KH + 1) / 2;  // 18 K-steps of two taps
 // INMODE 2: the same from uint8 frames (N,T,H,W,C) as the video decoder leaves them: (float)u8 - mean[c], rounded to bf16
 // exactly as INMODE 1 rounds the f32 value (bit-identical outputs for the same pixels), a quarter of the bytes over
 // PCIe and HBM (test_engine_rel.py:420-520 hands the network mean-subtracted f32 frames).
+#ifdef TRACE_STEM_NT
+#define STEM_LD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define STEM_LD(ptr) (*(ptr))
+#endif
 template <int INMODE>
 __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
   constexpr bool F32IN = INMODE != 0;   // the patch is built by the lanes (not LDS-DMA)
@@ -1003,7 +1008,7 @@ __global__ __launch_bounds__(256) void stem16_bf16_kernel(const IgemmParams p) {
             okc[r7][e] = ok && (unsigned)x < (unsigned)W;
             const int xc = min(max(x, 0), W - 1);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) raw[r7][e][c] = base[(c < C ? c : 0) * cstride + xc];
+            for (int c = 0; c < 3; ++c) raw[r7][e][c] = STEM_LD(base + (c < C ? c : 0) * cstride + xc);
           }
         } else {
           const uint8_t* base = p.in_u8 + ((((long long)n * T + tc) * H + yc) * W) * C;
