@@ -66,6 +66,71 @@ __global__ __launch_bounds__(256) void stream_kernel(const uint4* __restrict__ w
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[g * 256 + threadIdx.x] = acc;
 }
 
+__global__ void fill_kernel(uint4* p, long long n, uint32_t seed);
+
+// The FC's own fetch pattern without its arithmetic: per K-step a wave issues PIECES LDS-DMA loads of 1 KiB (4 = the
+// weight block alone, 9 = weight block + a 160-row activation tile from an L2-resident buffer) into a 3-stage ring,
+// waits for the step before last (counted vmcnt) and passes a barrier - the cadence of igemm3's loop.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int PIECES, int NT>
+__global__ __launch_bounds__(256) void dma_ring_kernel(const uint4* __restrict__ w, const uint4* __restrict__ act,
+                                                       uint4* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = PIECES * 4 * 1024;
+  const int g = blockIdx.x, tile = g % TILES, slice = g / TILES;
+  const int ks0 = slice * PER, ks1 = min(ks0 + PER, KSTEPS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto issue = [&](int ks, int stage) {
+    const char* src = reinterpret_cast<const char*>(w + ((long long)tile * KSTEPS + ks) * (BLOCK / 16)) + wave * 1024 + lane * 16;
+    char* dst = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const char* p = i < 4 ? src + i * 4096
+                            : reinterpret_cast<const char*>(act) + ((ks * 5 + (i - 4)) % 1280) * 4096 + wave * 1024 + lane * 16;
+      if (NT && i < 4) __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + i * 4096), 16, 0, 2);
+      else __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + i * 4096), 16, 0, 0);
+    }
+  };
+  issue(ks0, 0);
+  if (ks0 + 1 < ks1) issue(ks0 + 1, 1);
+  uint32_t acc = 0;
+  int st = 0;
+  for (int ks = ks0; ks < ks1; ++ks) {
+    if (ks + 1 < ks1) {
+      if (PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ks + 2 < ks1) issue(ks + 2, (st + 2) % 3);
+    acc ^= *reinterpret_cast<const uint32_t*>(smem + st * STAGE + threadIdx.x * 16);   // one word per lane: keeps the ring alive
+    st = (st + 1) % 3;
+  }
+  if (acc == 0x12345678u) sink[g * 256 + threadIdx.x] = make_uint4(acc, 0, 0, 0);
+}
+
+template <int PIECES, int NT>
+static void run_dma(const char* name, const uint4* w, const uint4* act, uint4* sink, uint4* flush, long long flush_n) {
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  CHECK(hipFuncSetAttribute((const void*)dma_ring_kernel<PIECES, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PIECES * 4096));
+  float best = 1e30f;
+  for (int r = 0; r < 6; ++r) {
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, flush, flush_n, (uint32_t)r);
+    CHECK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((dma_ring_kernel<PIECES, NT>), dim3(TILES * SLICES), dim3(256), 3 * PIECES * 4096, 0, w, act, sink);
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    if (r) best = ms < best ? ms : best;
+  }
+  printf("%-34s best %7.1f us  %5.2f TB/s of weights\n", name, best * 1e3, (double)TILES * KSTEPS * BLOCK / (best * 1e-3) * 1e-12);
+}
+
 __global__ void fill_kernel(uint4* p, long long n, uint32_t seed) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long st = (long long)gridDim.x * blockDim.x;
@@ -137,5 +202,14 @@ int main() {
   run<2, 4>("linear", w, sink, flush, flush_n);
   run<2, 8>("linear", w, sink, flush, flush_n);
   }
+  uint4* act;
+  CHECK(hipMalloc(&act, 1280 * 4096));
+  hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, 0, act, (long long)1280 * 256, 9u);
+  CHECK(hipDeviceSynchronize());
+  printf("-- LDS-DMA ring at the FC's cadence, no arithmetic (behind a writer)\n");
+  run_dma<4, 0>("ring, weights only, plain", w, act, sink, flush, flush_n);
+  run_dma<4, 1>("ring, weights only, nt", w, act, sink, flush, flush_n);
+  run_dma<9, 0>("ring, weights + act tile, plain", w, act, sink, flush, flush_n);
+  run_dma<9, 1>("ring, weights + act tile, nt", w, act, sink, flush, flush_n);
   return 0;
 }
