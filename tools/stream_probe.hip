@@ -73,21 +73,41 @@ __global__ void fill_kernel(uint4* p, long long n, uint32_t seed);
 // waits for the step before last (counted vmcnt) and passes a barrier - the cadence of igemm3's loop.
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-template <int PIECES, int NT>
+// ACT 0: the activation tile comes from a small L2-resident buffer; 1: from a 160 x 100352 row-major matrix as the FC
+// reads it (row m, K-step ks = 128 bytes at m * 200704 + ks * 128: 160 separate lines per K-step); 2: from the same
+// 32 MB laid out K-step-major ([ks][160 rows][128 B]: one contiguous 20 KiB block per K-step)
+template <int PIECES, int NT, int ACT = 0>
 __global__ __launch_bounds__(256) void dma_ring_kernel(const uint4* __restrict__ w, const uint4* __restrict__ act,
                                                        uint4* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int STAGE = PIECES * 4 * 1024;
-  const int g = blockIdx.x, tile = g % TILES, slice = g / TILES;
-  const int ks0 = slice * PER, ks1 = min(ks0 + PER, KSTEPS);
+  const int g = blockIdx.x;
+  int tile = g % TILES, slice = g / TILES, per = PER;
+  if (ACT >= 3) {          // 32 K-slices of 49 K-steps (768 workgroups); ACT 4: slices pinned to XCDs (workgroup g runs on XCD g % 8)
+    per = 49;
+    if (ACT == 4) {
+      const int q = g >> 3;
+      slice = (g & 7) + 8 * (q / TILES);
+      tile = q % TILES;
+    }
+  }
+  const int ks0 = slice * per, ks1 = min(ks0 + per, KSTEPS);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto issue = [&](int ks, int stage) {
     const char* src = reinterpret_cast<const char*>(w + ((long long)tile * KSTEPS + ks) * (BLOCK / 16)) + wave * 1024 + lane * 16;
     char* dst = smem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-      const char* p = i < 4 ? src + i * 4096
-                            : reinterpret_cast<const char*>(act) + ((ks * 5 + (i - 4)) % 1280) * 4096 + wave * 1024 + lane * 16;
+      const char* p;
+      if (i < 4) {
+        p = src + i * 4096;
+      } else if (ACT == 0) {
+        p = reinterpret_cast<const char*>(act) + ((ks * 5 + (i - 4)) % 1280) * 4096 + wave * 1024 + lane * 16;
+      } else {
+        const int row = (i - 4) * 32 + wave * 8 + (lane >> 3);   // 0..159
+        p = ACT != 2 ? reinterpret_cast<const char*>(act) + (long long)row * (KSTEPS * 128) + ks * 128 + (lane & 7) * 16
+                     : reinterpret_cast<const char*>(act) + ((long long)ks * 160 + row) * 128 + (lane & 7) * 16;
+      }
       if (NT && i < 4) __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + i * 4096), 16, 0, 2);
       else __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(dst + i * 4096), 16, 0, 0);
     }
@@ -111,17 +131,17 @@ __global__ __launch_bounds__(256) void dma_ring_kernel(const uint4* __restrict__
   if (acc == 0x12345678u) sink[g * 256 + threadIdx.x] = make_uint4(acc, 0, 0, 0);
 }
 
-template <int PIECES, int NT>
+template <int PIECES, int NT, int ACT = 0>
 static void run_dma(const char* name, const uint4* w, const uint4* act, uint4* sink, uint4* flush, long long flush_n) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  CHECK(hipFuncSetAttribute((const void*)dma_ring_kernel<PIECES, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PIECES * 4096));
+  CHECK(hipFuncSetAttribute((const void*)dma_ring_kernel<PIECES, NT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PIECES * 4096));
   float best = 1e30f;
   for (int r = 0; r < 6; ++r) {
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, flush, flush_n, (uint32_t)r);
     CHECK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((dma_ring_kernel<PIECES, NT>), dim3(TILES * SLICES), dim3(256), 3 * PIECES * 4096, 0, w, act, sink);
+    hipLaunchKernelGGL((dma_ring_kernel<PIECES, NT, ACT>), dim3(TILES * (ACT >= 3 ? 32 : SLICES)), dim3(256), 3 * PIECES * 4096, 0, w, act, sink);
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));
     float ms;
@@ -211,5 +231,13 @@ int main() {
   run_dma<4, 1>("ring, weights only, nt", w, act, sink, flush, flush_n);
   run_dma<9, 0>("ring, weights + act tile, plain", w, act, sink, flush, flush_n);
   run_dma<9, 1>("ring, weights + act tile, nt", w, act, sink, flush, flush_n);
+  uint4* act32;
+  CHECK(hipMalloc(&act32, (size_t)160 * KSTEPS * 128));
+  hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, act32, (long long)160 * KSTEPS * 8, 11u);
+  CHECK(hipDeviceSynchronize());
+  run_dma<9, 1, 1>("  act from 160 x 100352 row-major", w, act32, sink, flush, flush_n);
+  run_dma<9, 1, 2>("  act K-step-major (20 KiB blocks)", w, act32, sink, flush, flush_n);
+  run_dma<9, 1, 3>("  row-major act, 32 slices", w, act32, sink, flush, flush_n);
+  run_dma<9, 1, 4>("  row-major act, 32 slices on XCDs", w, act32, sink, flush, flush_n);
   return 0;
 }
